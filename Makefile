@@ -10,7 +10,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fa
            -fvisibility=hidden -Wall -Wno-unused-function -Iinclude
 SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip
 OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
-HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp include/gulon_hip.h
+HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.h
 
 all: $(LIB) oracle
 

@@ -1,15 +1,690 @@
-// KMeans / ProductQuantizer entry points (KMeans.scala, ProductQuantizer.scala).
-#include "common.hpp"
+// KMeans / ProductQuantizer on gfx950 (KMeans.scala, ProductQuantizer.scala).
+//
+//   assign   exact argmin of  offsets[c] - 2*(x . c)  in the JVM's unfused, sequential
+//            binary32 order, including the  d == min && rng.nextBoolean()  tie-break:
+//            pass 1 computes the draw-free argmin and the number of RNG draws each row
+//            makes; a segmented prefix sum places every row in its java.util.Random
+//            stream (one stream per rng_batch rows); pass 2 replays only the rows that
+//            draw, after an O(log) LCG jump-ahead.
+//   update   KMeans.fromAssignment: order-dependent running mean  c += (x - c)/n.
+//            Rows are bucketed by cluster with a STABLE counting sort, then every
+//            (cluster, dim) chain runs sequentially in row order.
+//   train    KMeans.computeClusters loop for a batch of independent problems
+//            (ProductQuantizer.apply = m problems, seed = quantizer index).
+#include "kmeans.hpp"
+
+namespace gulon {
+
+// ---------------------------------------------------------------------------
+// centroid prep: KMeans.apply offsets (KMeans.scala:170-186) + zero-padded copy.
+// Zero padding is exact: d + 0*0 == d for every binary32 d (a -0 partial sum may
+// become +0, which no comparison or later operation here can observe).
+// ---------------------------------------------------------------------------
+__global__ void prep_centroids(const float *__restrict__ C, int k, int s, int smax, float *__restrict__ Cpad,
+                               float *__restrict__ off) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  float acc = 0.f;
+  for (int j = 0; j < s; j++) {
+    float x = C[(size_t)c * s + j];
+    acc += x * x;
+    Cpad[(size_t)c * smax + j] = x;
+  }
+  for (int j = s; j < smax; j++) Cpad[(size_t)c * smax + j] = 0.f;
+  off[c] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// pass 1: draw-free argmin + number of draws (KMeans.scala:33-54 / :76-97 with
+// rng.nextBoolean() read as false).  assign[] is written only when some centroid
+// won, exactly like the reference (NaN distances never win).
+// ---------------------------------------------------------------------------
+template <int SMAX>
+__global__ __launch_bounds__(256) void assign_exact(const float *__restrict__ X, int n, int ld, int from, int s,
+                                                    const float *__restrict__ Cpad, const float *__restrict__ off,
+                                                    int k, const int *__restrict__ rows, int nrows,
+                                                    int *__restrict__ assign, unsigned *__restrict__ ties,
+                                                    unsigned long long *__restrict__ tie_total) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  int i = -1;
+  if (t < nrows) i = rows ? rows[t] : t;
+  float x[SMAX];
+#pragma unroll
+  for (int j = 0; j < SMAX; j++) x[j] = 0.f;
+  if (i >= 0) {
+    const float *row = X + (size_t)i * ld + from;
+#pragma unroll
+    for (int j = 0; j < SMAX; j++)
+      if (j < s) x[j] = row[j];
+  }
+  float mn = FLT_MAX;
+  int best = -1;
+  unsigned nt = 0;
+  for (int c = 0; c < k; c++) {
+    const float *cc = Cpad + (size_t)c * SMAX;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMAX; j++) d += x[j] * cc[j];
+    d = off[c] - 2 * d;
+    if (d < mn) { mn = d; best = c; }
+    else if (d == mn) nt++;
+  }
+  if (i >= 0) {
+    if (best >= 0) assign[i] = best;
+    ties[i] = nt;
+  } else {
+    nt = 0;
+  }
+  // any draws in this launch?
+  unsigned long long wsum = nt;
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
+  if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(tie_total, wsum);
+}
+
+// generic dimension (s > 128): x re-read from memory for every centroid
+__global__ __launch_bounds__(256) void assign_exact_generic(const float *__restrict__ X, int n, int ld, int from,
+                                                            int s, const float *__restrict__ Cpad, int smax,
+                                                            const float *__restrict__ off, int k,
+                                                            const int *__restrict__ rows, int nrows,
+                                                            int *__restrict__ assign, unsigned *__restrict__ ties,
+                                                            unsigned long long *__restrict__ tie_total) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  int i = -1;
+  if (t < nrows) i = rows ? rows[t] : t;
+  unsigned nt = 0;
+  if (i >= 0) {
+    const float *row = X + (size_t)i * ld + from;
+    float mn = FLT_MAX;
+    int best = -1;
+    for (int c = 0; c < k; c++) {
+      const float *cc = Cpad + (size_t)c * smax;
+      float d = 0.f;
+      for (int j = 0; j < s; j++) d += row[j] * cc[j];
+      d = off[c] - 2 * d;
+      if (d < mn) { mn = d; best = c; }
+      else if (d == mn) nt++;
+    }
+    if (best >= 0) assign[i] = best;
+    ties[i] = nt;
+  }
+  unsigned long long wsum = nt;
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
+  if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(tie_total, wsum);
+}
+
+// ---------------------------------------------------------------------------
+// segmented exclusive prefix sum of ties[] (segments = rng_batch rows): where each
+// row's draws sit in its java.util.Random stream.
+// ---------------------------------------------------------------------------
+__device__ inline unsigned block_exclusive_scan_1024(unsigned v, unsigned *total, unsigned *lds /*>=16*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    unsigned w = lane < 16 ? lds[lane] : 0;
+    unsigned winc = w;
+    for (int o = 1; o < 16; o <<= 1) {
+      unsigned u = __shfl_up(winc, o);
+      if (lane >= o) winc += u;
+    }
+    if (lane < 16) lds[lane] = winc - w;   // exclusive wave offsets
+    if (lane == 15) lds[16] = winc;
+  }
+  __syncthreads();
+  unsigned res = inc - v + lds[wave];
+  *total = lds[16];
+  __syncthreads();
+  return res;
+}
+
+// grid (blocks_per_seg, nseg), 1024 threads
+__global__ __launch_bounds__(1024) void tie_block_sums(const unsigned *__restrict__ ties, int n, int seg_len,
+                                                       int bps, unsigned *__restrict__ local,
+                                                       unsigned *__restrict__ block_tot) {
+  __shared__ unsigned lds[32];
+  int seg = blockIdx.y, blk = blockIdx.x;
+  long long seg_begin = (long long)seg * seg_len;
+  long long seg_end = seg_begin + seg_len < n ? seg_begin + seg_len : n;
+  long long idx = seg_begin + (long long)blk * 1024 + threadIdx.x;
+  unsigned v = idx < seg_end ? ties[idx] : 0u;
+  unsigned tot;
+  unsigned ex = block_exclusive_scan_1024(v, &tot, lds);
+  if (idx < seg_end) local[idx] = ex;
+  if (threadIdx.x == 0) block_tot[(size_t)seg * bps + blk] = tot;
+}
+
+// one block per segment: exclusive scan of that segment's block totals
+__global__ __launch_bounds__(1024) void tie_block_scan(const unsigned *__restrict__ block_tot, int bps,
+                                                       unsigned long long *__restrict__ block_off) {
+  __shared__ unsigned lds[32];
+  __shared__ unsigned long long carry;
+  int seg = blockIdx.x;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < bps; base += 1024) {
+    int b = base + threadIdx.x;
+    unsigned v = b < bps ? block_tot[(size_t)seg * bps + b] : 0u;
+    unsigned tot;
+    unsigned ex = block_exclusive_scan_1024(v, &tot, lds);
+    unsigned long long c0 = carry;
+    if (b < bps) block_off[(size_t)seg * bps + b] = c0 + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c0 + tot;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 2: replay the rows that draw, with the RNG jumped to their stream position.
+// ---------------------------------------------------------------------------
+template <int SMAX>
+__global__ __launch_bounds__(256) void assign_resolve(const float *__restrict__ X, int n, int ld, int from, int s,
+                                                      const float *__restrict__ Cpad, int smax,
+                                                      const float *__restrict__ off, int k,
+                                                      const unsigned *__restrict__ ties,
+                                                      const unsigned *__restrict__ local,
+                                                      const unsigned long long *__restrict__ block_off, int seg_len,
+                                                      int bps, int *__restrict__ assign) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || ties[i] == 0) return;
+  int seg = i / seg_len;
+  int blk = (i - seg * seg_len) / 1024;
+  unsigned long long pos = block_off[(size_t)seg * bps + blk] + local[i];
+  JRandom rng(0);
+  rng.skip(pos);
+  const float *row = X + (size_t)i * ld + from;
+  float mn = FLT_MAX;
+  int best = -1;
+  for (int c = 0; c < k; c++) {
+    const float *cc = Cpad + (size_t)c * smax;
+    float d = 0.f;
+    for (int j = 0; j < s; j++) d += row[j] * cc[j];
+    d = off[c] - 2 * d;
+    if (d < mn || (d == mn && rng.next_boolean())) { best = c; mn = d; }
+  }
+  if (best >= 0) assign[i] = best;
+}
+
+// ---------------------------------------------------------------------------
+// misc small kernels
+// ---------------------------------------------------------------------------
+__global__ void gather_centroids(const float *__restrict__ X, int ld, int from, int s, const int *__restrict__ rows,
+                                 int k, float *__restrict__ C) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * s) return;
+  int c = t / s, j = t - c * s;
+  C[t] = X[(size_t)rows[c] * ld + from + j];
+}
+
+__global__ void count_mismatch(const int *__restrict__ a, const int *__restrict__ b, int n,
+                               unsigned *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool diff = i < n && a[i] != b[i];
+  if (__ballot(diff) && (threadIdx.x & 63) == 0) atomicOr(out, 1u);
+}
+
+__global__ void narrow_assign_u8(const int *__restrict__ a, long long n, uint8_t *__restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)a[i];
+}
+
+// ---------------------------------------------------------------------------
+// update: stable counting sort by cluster, then sequential chains
+// ---------------------------------------------------------------------------
+constexpr int SORT_ROWS_PER_WAVE = 2048;
+
+// per wave-chunk histogram: hist[chunk][k]
+__global__ __launch_bounds__(256) void sort_hist(const int *__restrict__ assign, int n, int k,
+                                                 unsigned *__restrict__ hist) {
+  extern __shared__ unsigned sh[];  // 4 * k
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned *h = sh + wave * k;
+  for (int c = lane; c < k; c += 64) h[c] = 0;
+  long long chunk = (long long)blockIdx.x * 4 + wave;
+  long long r0 = chunk * SORT_ROWS_PER_WAVE;
+  long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
+  for (long long r = r0 + lane; r < r1; r += 64) atomicAdd(&h[assign[r]], 1u);
+  if (r0 < n)
+    for (int c = lane; c < k; c += 64) hist[(size_t)chunk * k + c] = h[c];
+}
+
+// thread per cluster: exclusive scan over chunks; then cluster starts
+__global__ void sort_scan(unsigned *__restrict__ hist, long long nchunks, int k, unsigned *__restrict__ count,
+                          unsigned *__restrict__ start) {
+  extern __shared__ unsigned cnt[];  // k
+  for (int c = threadIdx.x; c < k; c += blockDim.x) {
+    unsigned run = 0;
+    for (long long ch = 0; ch < nchunks; ch++) {
+      unsigned v = hist[(size_t)ch * k + c];
+      hist[(size_t)ch * k + c] = run;
+      run += v;
+    }
+    cnt[c] = run;
+    count[c] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int c = 0; c < k; c++) { start[c] = run; run += cnt[c]; }
+  }
+}
+
+// each wave places its chunk's rows in order: order[start[c] + rank] = row
+__global__ __launch_bounds__(256) void sort_place(const int *__restrict__ assign, int n, int k,
+                                                  const unsigned *__restrict__ hist,
+                                                  const unsigned *__restrict__ start, int *__restrict__ order) {
+  extern __shared__ unsigned sh[];  // 4 * k running positions
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned *run = sh + wave * k;
+  long long chunk = (long long)blockIdx.x * 4 + wave;
+  long long r0 = chunk * SORT_ROWS_PER_WAVE;
+  if (r0 >= n) return;
+  long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
+  for (int c = lane; c < k; c += 64) run[c] = start[c] + hist[(size_t)chunk * k + c];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (long long base = r0; base < r1; base += 64) {
+    long long r = base + lane;
+    bool valid = r < r1;
+    int key = valid ? assign[r] : -1;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      int l = __ffsll((long long)todo) - 1;
+      int k0 = __shfl(key, l);
+      unsigned long long mk = __ballot(valid && key == k0);
+      unsigned b = run[k0];                      // wave-uniform read
+      if (valid && key == k0) order[b + __popcll(mk & lt)] = (int)r;
+      if (lane == l) run[k0] = b + __popcll(mk);
+      todo &= ~mk;
+    }
+  }
+}
+
+// one thread per (cluster, dim): c_j <- c_j + (x_j - c_j)/n over the cluster's rows
+// in row order (KMeans.scala:211-224).  IEEE division (__fdiv_rn), int->float RNE.
+__global__ __launch_bounds__(256) void update_chains(const float *__restrict__ X, int ld, int from, int s, int k,
+                                                     const int *__restrict__ order,
+                                                     const unsigned *__restrict__ count,
+                                                     const unsigned *__restrict__ start, float *__restrict__ C) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * s) return;
+  int c = t / s, j = t - c * s;
+  const unsigned len = count[c];
+  const int *ord = order + start[c];
+  const float *col = X + from + j;
+  float p = 0.f;
+  unsigned i = 0;
+  constexpr int U = 8;
+  for (; i + U <= len; i += U) {
+    float xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) xv[u] = col[(size_t)ord[i + u] * ld];
+#pragma unroll
+    for (int u = 0; u < U; u++) p = p + __fdiv_rn(xv[u] - p, (float)(int)(i + u + 1));
+  }
+  for (; i < len; i++) {
+    float xv = col[(size_t)ord[i] * ld];
+    p = p + __fdiv_rn(xv - p, (float)(int)(i + 1));
+  }
+  C[t] = p;
+}
+
+// ---------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------
+static int pick_smax(int s) {
+  if (s <= 4) return 4;
+  if (s <= 8) return 8;
+  if (s <= 16) return 16;
+  if (s <= 32) return 32;
+  if (s <= 64) return 64;
+  if (s <= 128) return 128;
+  return s;
+}
+
+void KmeansWorkspace::ensure(int n, int k, int s) {
+  int smax = pick_smax(s);
+  cpad.ensure((size_t)k * smax);
+  off.ensure(k);
+  ties.ensure((size_t)std::max(n, 1));
+  local.ensure((size_t)std::max(n, 1));
+  tie_total.ensure(1);
+  long long nchunks = ceil_div(std::max(n, 1), SORT_ROWS_PER_WAVE);
+  long long nchunks_pad = ((nchunks + 3) / 4) * 4;
+  hist.ensure((size_t)nchunks_pad * k);
+  count.ensure(k);
+  start.ensure(k);
+  order.ensure((size_t)std::max(n, 1));
+  mismatch.ensure(1);
+}
+
+// KMeans.assign / parAssign on device arrays.  d_assign is written only where a
+// centroid won (caller initialises it).  rng_batch <= 0: one stream over all rows.
+void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
+                       int rng_batch, int *d_assign, hipStream_t st) {
+  if (n <= 0) return;
+  ws.ensure(n, k, s);
+  const int smax = pick_smax(s);
+  hipLaunchKernelGGL(prep_centroids, dim3(ceil_div(k, 64)), dim3(64), 0, st, dC, k, s, smax, ws.cpad.p, ws.off.p);
+  HIP_CHECK(hipMemsetAsync(ws.tie_total.p, 0, sizeof(unsigned long long), st));
+  const int grid = ceil_div(n, 256);
+#define AE(S)                                                                                                    \
+  hipLaunchKernelGGL(assign_exact<S>, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, ws.off.p, k, \
+                     (const int *)nullptr, n, d_assign, ws.ties.p, ws.tie_total.p)
+  switch (smax) {
+    case 4: AE(4); break;
+    case 8: AE(8); break;
+    case 16: AE(16); break;
+    case 32: AE(32); break;
+    case 64: AE(64); break;
+    case 128: AE(128); break;
+    default:
+      hipLaunchKernelGGL(assign_exact_generic, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax,
+                         ws.off.p, k, (const int *)nullptr, n, d_assign, ws.ties.p, ws.tie_total.p);
+  }
+#undef AE
+  HIP_CHECK(hipGetLastError());
+  unsigned long long total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, ws.tie_total.p, sizeof(total), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  ws.last_draws = total;
+  if (total == 0) return;
+  // place every drawing row in its RNG stream and replay it
+  const int seg_len = rng_batch > 0 ? rng_batch : n;
+  const int nseg = ceil_div(n, seg_len);
+  const int bps = ceil_div(seg_len < n ? seg_len : n, 1024);
+  ws.block_tot.ensure((size_t)nseg * bps);
+  ws.block_off.ensure((size_t)nseg * bps);
+  hipLaunchKernelGGL(tie_block_sums, dim3(bps, nseg), dim3(1024), 0, st, ws.ties.p, n, seg_len, bps, ws.local.p,
+                     ws.block_tot.p);
+  hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, st, ws.block_tot.p, bps, ws.block_off.p);
+  hipLaunchKernelGGL(assign_resolve<0>, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax, ws.off.p,
+                     k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, d_assign);
+  HIP_CHECK(hipGetLastError());
+}
+
+// KMeans.fromAssignment on device arrays -> dC (k x s)
+void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
+                       const int *d_assign, float *dC, hipStream_t st) {
+  ws.ensure(n, k, s);
+  if (n <= 0) {
+    HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(float) * (size_t)k * s, st));
+    return;
+  }
+  long long nchunks = ceil_div(n, SORT_ROWS_PER_WAVE);
+  int blocks = ceil_div(nchunks, 4);
+  size_t shm = sizeof(unsigned) * 4 * (size_t)k;
+  hipLaunchKernelGGL(sort_hist, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p);
+  hipLaunchKernelGGL(sort_scan, dim3(1), dim3(256), sizeof(unsigned) * (size_t)k, st, ws.hist.p, nchunks, k,
+                     ws.count.p, ws.start.p);
+  hipLaunchKernelGGL(sort_place, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p, ws.start.p,
+                     ws.order.p);
+  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * s, 64)), dim3(64), 0, st, dX, ld, from, s, k,
+                     ws.order.p, ws.count.p, ws.start.p, dC);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void validate_assignments(const int32_t *a, int n, int k) {
+  for (int i = 0; i < n; i++)
+    GULON_REQUIRE(a[i] >= 0 && a[i] < k, "assignment %d at row %d is outside [0,%d)", a[i], i, k);
+}
+
+// SummaryStats builder over MathUtils.distance(prev_c, next_c) (KMeans.scala:160-168,
+// MathUtils.scala:43-57,85-98): k values, host side.
+static void step_stats(const float *prev, const float *next, int k, int s, gulon_kmeans_report *r) {
+  int n = 0;
+  float m = 0.f, ss = 0.f;
+  for (int c = 0; c < k; c++) {
+    float sum = 0.f;
+    for (int j = 0; j < s; j++) {
+      float dx = next[(size_t)c * s + j] - prev[(size_t)c * s + j];
+      sum += dx * dx;
+    }
+    float x = (float)std::sqrt((double)sum);
+    n += 1;
+    float m0 = m;
+    m = m0 + (x - m0) / (float)n;
+    ss = ss + (x - m0) * (x - m);
+  }
+  r->step_count = n;
+  r->step_mean = m;
+  r->step_s = ss;
+}
+
+// KMeans.computeClusters (KMeans.scala:134-157) for `np` independent problems
+// (from[p], s[p], seed[p]) over the same n x ld data, run iteration-synchronously.
+// c_out[p] receives k x s[p] floats.
+void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from, const int *sdim, const int *seeds,
+                        int k, int max_iterations, float *const *c_out, gulon_kmeans_report *reports,
+                        int max_reports, int32_t *n_reports) {
+  GULON_REQUIRE(n >= 1, "KMeans.init needs at least one row (n = %d)", n);   // rng.nextInt(0) throws on the JVM
+  hipStream_t st = nullptr;
+  KmeansWorkspace ws;
+  struct Prob {
+    DevBuf<float> c_prev, c_next;
+    DevBuf<int> a_prev, a_next;
+    std::vector<float> h_prev, h_next;
+    bool done = false;
+    int nrep = 0;
+  };
+  std::vector<Prob> P(np);
+  auto push_report = [&](int p, const gulon_kmeans_report &r) {
+    if (reports && P[p].nrep < max_reports) reports[(size_t)p * max_reports + P[p].nrep] = r;
+    P[p].nrep++;
+  };
+  DevBuf<int> d_rows(k);
+  for (int p = 0; p < np; p++) {
+    const int s = sdim[p];
+    Prob &pr = P[p];
+    pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
+    pr.a_prev.alloc(n); pr.a_next.alloc(n);
+    pr.h_prev.resize((size_t)k * s); pr.h_next.resize((size_t)k * s);
+    // KMeans.init (KMeans.scala:188-196)
+    std::vector<int> rows(k);
+    JRandom rng((int64_t)seeds[p]);
+    for (int c = 0; c < k; c++) rows[c] = rng.next_int(n);
+    d_rows.upload(rows.data(), k, st);
+    hipLaunchKernelGGL(gather_centroids, dim3(ceil_div((long long)k * s, 256)), dim3(256), 0, st, dX, ld, from[p], s,
+                       d_rows.p, k, pr.c_prev.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, st));
+    kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_prev.p, k, 25000, pr.a_prev.p, st);
+    pr.c_prev.download(pr.h_prev.data(), (size_t)k * s, st);
+    push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  DevBuf<unsigned> mism(np);
+  std::vector<unsigned> h_mism(np);
+  for (int i = 0; i <= max_iterations;) {
+    bool any = false;
+    HIP_CHECK(hipMemsetAsync(mism.p, 0, sizeof(unsigned) * np, st));
+    for (int p = 0; p < np; p++) {
+      Prob &pr = P[p];
+      if (pr.done) continue;
+      any = true;
+      const int s = sdim[p];
+      kmeans_update_dev(ws, dX, n, ld, from[p], s, k, pr.a_prev.p, pr.c_next.p, st);
+      HIP_CHECK(hipMemsetAsync(pr.a_next.p, 0, sizeof(int) * (size_t)n, st));   // fresh Array[Int] per parAssign
+      kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_next.p, k, 25000, pr.a_next.p, st);
+      hipLaunchKernelGGL(count_mismatch, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr.a_prev.p, pr.a_next.p, n,
+                         mism.p + p);
+      pr.c_next.download(pr.h_next.data(), (size_t)k * s, st);
+    }
+    if (!any) break;
+    mism.download(h_mism.data(), np, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    bool all_conv = true;
+    for (int p = 0; p < np; p++) {
+      Prob &pr = P[p];
+      if (pr.done) continue;
+      bool converged = h_mism[p] == 0;                       // Arrays.equals(prev, next)
+      gulon_kmeans_report r{i, converged ? 1 : 0, 0, 0.f, 0.f};
+      step_stats(pr.h_prev.data(), pr.h_next.data(), k, sdim[p], &r);
+      push_report(p, r);
+      std::swap(pr.c_prev, pr.c_next);
+      std::swap(pr.a_prev, pr.a_next);
+      std::swap(pr.h_prev, pr.h_next);
+      if (converged) pr.done = true; else all_conv = false;
+    }
+    if (all_conv) break;
+    i++;
+  }
+  for (int p = 0; p < np; p++) {
+    memcpy(c_out[p], P[p].h_prev.data(), sizeof(float) * (size_t)k * sdim[p]);
+    if (n_reports) n_reports[p] = P[p].nrep;
+  }
+}
+
+}  // namespace gulon
 
 using namespace gulon;
 
-#define NOT_YET(name) \
-  return guarded([&] { GULON_UNSUPPORTED(true, name " is not implemented yet"); })
+static void check_slice(const gulon_dataset *ds, int from, int s, int k) {
+  GULON_REQUIRE(ds != nullptr, "dataset is null");
+  GULON_REQUIRE(from >= 0 && s >= 0 && from + s <= ds->d, "column slice [%d,%d) outside [0,%d)", from, from + s,
+                ds ? ds->d : 0);
+  GULON_REQUIRE(k >= 1, "numClusters must be >= 1 (got %d)", k);
+}
 
-GULON_API int32_t gulon_kmeans_init(const gulon_dataset *, int32_t, int32_t, int32_t, int32_t, float *, int32_t *) { NOT_YET("gulon_kmeans_init"); }
-GULON_API int32_t gulon_kmeans_assign(const gulon_dataset *, int32_t, int32_t, const float *, int32_t, int32_t, int32_t *) { NOT_YET("gulon_kmeans_assign"); }
-GULON_API int32_t gulon_kmeans_update(const gulon_dataset *, int32_t, int32_t, int32_t, const int32_t *, float *) { NOT_YET("gulon_kmeans_update"); }
-GULON_API int32_t gulon_kmeans_iterate(const gulon_dataset *, int32_t, int32_t, const float *, int32_t, int32_t, float *) { NOT_YET("gulon_kmeans_iterate"); }
-GULON_API int32_t gulon_kmeans_train(const gulon_dataset *, int32_t, int32_t, int32_t, int32_t, int32_t, float *, gulon_kmeans_report *, int32_t, int32_t *) { NOT_YET("gulon_kmeans_train"); }
-GULON_API int32_t gulon_pq_train(const gulon_dataset *, int32_t, int32_t, int32_t, float *, gulon_kmeans_report *, int32_t, int32_t *) { NOT_YET("gulon_pq_train"); }
-GULON_API int32_t gulon_pq_encode(const gulon_dataset *, int32_t, int32_t, const float *, uint8_t *) { NOT_YET("gulon_pq_encode"); }
+GULON_API int32_t gulon_kmeans_init(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k, int32_t seed,
+                                    float *c_out, int32_t *rows_out) {
+  return guarded([&] {
+    check_slice(ds, from, s, k);
+    GULON_REQUIRE(ds->n >= 1, "KMeans.init needs at least one row");
+    std::vector<int> rows(k);
+    JRandom rng((int64_t)seed);
+    for (int c = 0; c < k; c++) rows[c] = rng.next_int(ds->n);
+    if (rows_out) memcpy(rows_out, rows.data(), sizeof(int) * k);
+    if (c_out && s > 0) {
+      DevBuf<int> dr; dr.upload(rows.data(), k);
+      DevBuf<float> dc((size_t)k * s);
+      hipLaunchKernelGGL(gather_centroids, dim3(ceil_div((long long)k * s, 256)), dim3(256), 0, 0, ds->x.p, ds->d,
+                         from, s, dr.p, k, dc.p);
+      HIP_CHECK(hipGetLastError());
+      dc.download(c_out, (size_t)k * s);
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+  });
+}
+
+GULON_API int32_t gulon_kmeans_assign(const gulon_dataset *ds, int32_t from, int32_t s, const float *centroids,
+                                      int32_t k, int32_t rng_batch, int32_t *assignments) {
+  return guarded([&] {
+    check_slice(ds, from, s, k);
+    if (ds->n == 0) return;
+    KmeansWorkspace ws;
+    DevBuf<float> dc; dc.upload(centroids, std::max<size_t>((size_t)k * s, 1));
+    DevBuf<int> da; da.upload(assignments, ds->n);
+    kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, rng_batch, da.p, nullptr);
+    da.download(assignments, ds->n);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+GULON_API int32_t gulon_kmeans_update(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k,
+                                      const int32_t *assignments, float *c_out) {
+  return guarded([&] {
+    check_slice(ds, from, s, k);
+    if (s == 0) return;
+    validate_assignments(assignments, ds->n, k);
+    KmeansWorkspace ws;
+    DevBuf<int> da; da.upload(assignments, std::max(ds->n, 1));
+    DevBuf<float> dc((size_t)k * s);
+    kmeans_update_dev(ws, ds->x.p, ds->n, ds->d, from, s, k, da.p, dc.p, nullptr);
+    dc.download(c_out, (size_t)k * s);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+GULON_API int32_t gulon_kmeans_iterate(const gulon_dataset *ds, int32_t from, int32_t s, const float *c_in, int32_t k,
+                                       int32_t iters, float *c_out) {
+  return guarded([&] {
+    check_slice(ds, from, s, k);
+    GULON_REQUIRE(iters >= 0, "iters must be >= 0");
+    if (s == 0) return;
+    KmeansWorkspace ws;
+    DevBuf<float> dc; dc.upload(c_in, (size_t)k * s);
+    DevBuf<int> da(std::max(ds->n, 1));
+    HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)std::max(ds->n, 1)));   // one array reused (KMeans.scala:101)
+    for (int it = 0; it < iters; it++) {
+      kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, 0, da.p, nullptr);
+      kmeans_update_dev(ws, ds->x.p, ds->n, ds->d, from, s, k, da.p, dc.p, nullptr);
+    }
+    dc.download(c_out, (size_t)k * s);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+GULON_API int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int32_t k,
+                                     int32_t max_iterations, int32_t seed, float *c_out,
+                                     gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports) {
+  return guarded([&] {
+    check_slice(ds, from, s, k);
+    GULON_REQUIRE(s >= 1, "dimension must be >= 1");
+    float *outs[1] = {c_out};
+    kmeans_train_batch(ds->x.p, ds->n, ds->d, 1, &from, &s, &seed, k, max_iterations, outs, reports, max_reports,
+                       n_reports);
+  });
+}
+
+GULON_API int32_t gulon_pq_train(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
+                                 float *cents_out, gulon_kmeans_report *reports, int32_t max_reports,
+                                 int32_t *n_reports) {
+  return guarded([&] {
+    GULON_REQUIRE(ds != nullptr, "dataset is null");
+    GULON_REQUIRE(m >= 1 && m <= ds->d && k >= 1, "bad quantizer shape m=%d k=%d d=%d", m, k, ds->d);
+    std::vector<int> from, until, sdim(m), seeds(m);
+    subvectors(ds->d, m, from, until);
+    std::vector<float *> outs(m);
+    for (int j = 0; j < m; j++) {
+      sdim[j] = until[j] - from[j];
+      seeds[j] = j;                                   // ProductQuantizer.scala:139
+      outs[j] = cents_out + (size_t)k * from[j];
+    }
+    kmeans_train_batch(ds->x.p, ds->n, ds->d, m, from.data(), sdim.data(), seeds.data(), k, max_iterations,
+                       outs.data(), reports, max_reports, n_reports);
+  });
+}
+
+GULON_API int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
+                                  uint8_t *codes_out) {
+  return guarded([&] {
+    GULON_REQUIRE(ds != nullptr, "dataset is null");
+    GULON_REQUIRE(m >= 1 && m <= ds->d && k >= 1, "bad quantizer shape m=%d k=%d d=%d", m, k, ds->d);
+    int width = -1;
+    GULON_REQUIRE(gulon_coder_width(k, &width) == GULON_OK, "too many clusters: %d", k);
+    const int n = ds->n;
+    int bytes = 0;
+    gulon_coder_bytes(width, n, &bytes);
+    if (n == 0 || width == 0) return;   // Coder0: empty codes
+    std::vector<int> from, until;
+    subvectors(ds->d, m, from, until);
+    KmeansWorkspace ws;
+    DevBuf<float> dc;
+    DevBuf<int> da(n);
+    DevBuf<uint8_t> d8(n);
+    std::vector<int> h_idx;
+    for (int j = 0; j < m; j++) {
+      const int s = until[j] - from[j];
+      dc.upload(cents + (size_t)k * from[j], (size_t)k * s);
+      HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)n));
+      kmeans_assign_dev(ws, ds->x.p, n, ds->d, from[j], s, dc.p, k, 0, da.p, nullptr);   // serial assign
+      uint8_t *out = codes_out + (size_t)j * bytes;
+      if (width == 8) {                                                                   // Coder8: idx.toByte
+        hipLaunchKernelGGL(narrow_assign_u8, dim3(ceil_div(n, 256)), dim3(256), 0, 0, da.p, (long long)n, d8.p);
+        HIP_CHECK(hipGetLastError());
+        d8.download(out, n);
+        HIP_CHECK(hipDeviceSynchronize());
+      } else {
+        h_idx.resize(n);
+        da.download(h_idx.data(), n);
+        HIP_CHECK(hipDeviceSynchronize());
+        GULON_REQUIRE(gulon_coder_build(width, h_idx.data(), n, out) == GULON_OK, "coder failed");
+      }
+    }
+  });
+}

@@ -1,0 +1,156 @@
+"""GPU parity tests for the build path: KMeans init/assign/parAssign/fromAssignment/
+computeClusters/iterate and ProductQuantizer train/encode vs the CPU oracle.
+Everything is compared bit for bit (centroids as uint32 views, assignments and codes as ints)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gulon_amd
+    assert gulon_amd.native.device_count() >= 1
+    return gulon_amd
+
+
+def _clustered(seed, n, d, kc=8):
+    rng = np.random.default_rng(seed)
+    cents = rng.uniform(-5, 5, (kc, d))
+    scales = rng.uniform(0.1, 1.5, (kc, d))
+    which = rng.integers(0, kc, n)
+    return (cents[which] + rng.standard_normal((n, d)) * scales[which]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,d,frm,s,k,seed", [(3000, 16, 0, 4, 16, 0), (5000, 20, 7, 5, 25, 3), (70000, 8, 0, 8, 256, 1),
+                                              (4000, 40, 4, 33, 7, 2), (2000, 140, 3, 130, 5, 4), (500, 3, 1, 1, 3, 9)])
+def test_init_assign_update_bit_exact(oracle, g, n, d, frm, s, k, seed):
+    X = _clustered(seed, n, d)
+    dm = g.DeviceMatrix.from_host(X)
+    v = g.Vectors(dm, frm, frm + s)
+    km = g.KMeans.init(k, v, seed)
+    C0, _ = oracle.kmeans_init(X, frm, s, k, seed)
+    assert np.array_equal(bits(km.centroids), bits(C0))
+    for rb, fn in ((0, km.assign), (25000, km.par_assign)):
+        a = fn(v)
+        assert np.array_equal(a, oracle.kmeans_assign(X, frm, s, C0, rb))
+    nxt = g.KMeans.from_assignment(k, s, v, a)
+    assert np.array_equal(bits(nxt.centroids), bits(oracle.kmeans_from_assignment(X, frm, s, k, a)))
+
+
+def test_tie_break_rng_across_batches(oracle, g):
+    """Duplicate / zero centroids: every row draws from java.util.Random; the stream restarts
+    every 25 000 rows in parAssign but not in the serial assign (KMeans.scala:28 vs :71)."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    X = rng.standard_normal((n, 2)).astype(np.float32)
+    dm = g.DeviceMatrix.from_host(X)
+    v = g.Vectors(dm, 0, 2)
+    for C in (np.zeros((4, 2), np.float32),
+              np.array([[0.5, 0.5], [0.5, 0.5], [-1, 0], [-1, 0], [0.5, 0.5]], np.float32)):
+        km = g.KMeans(2, C)
+        for rb, fn in ((0, km.assign), (25000, km.par_assign)):
+            a = fn(v)
+            exp = oracle.kmeans_assign(X, 0, 2, C, rb)
+            assert np.array_equal(a, exp)
+            assert len(set(a.tolist())) > 1
+    # duplicated data rows => duplicate init centroids (init samples with replacement)
+    X2 = np.repeat(rng.standard_normal((50, 3)).astype(np.float32), 40, axis=0)
+    dm2 = g.DeviceMatrix.from_host(X2)
+    v2 = g.Vectors(dm2, 0, 3)
+    km = g.KMeans.init(32, v2, 0)
+    C0, _ = oracle.kmeans_init(X2, 0, 3, 32, 0)
+    assert np.array_equal(km.par_assign(v2), oracle.kmeans_assign(X2, 0, 3, C0, 25000))
+    assert np.array_equal(km.assign(v2), oracle.kmeans_assign(X2, 0, 3, C0, 0))
+
+
+def test_assign_keeps_untouched_rows_on_nan(oracle, g):
+    X = np.ones((100, 2), np.float32)
+    X[7] = np.nan
+    C = np.array([[0, 0], [1, 1]], np.float32)
+    pre = np.full(100, 1, np.int32)
+    pre[7] = 0
+    a = g.KMeans(2, C).assign(g.Vectors(g.DeviceMatrix.from_host(X), 0, 2), pre.copy())
+    exp = oracle.kmeans_assign(X, 0, 2, C, 0, pre.copy())
+    assert np.array_equal(a, exp) and a[7] == 0
+
+
+@pytest.mark.parametrize("n,d,frm,s,k,iters,seed", [(4000, 12, 0, 6, 8, 100, 0), (30000, 16, 8, 8, 64, 5, 2),
+                                                    (2000, 4, 0, 4, 300, 3, 1)])
+def test_compute_clusters_bit_exact(oracle, g, n, d, frm, s, k, iters, seed):
+    X = _clustered(seed + 10, n, d)
+    reps = []
+    cfg = g.KMeansConfig(k, iters, seed, reps.append)
+    km = g.KMeans.compute_clusters(g.Vectors(g.DeviceMatrix.from_host(X), frm, frm + s), cfg)
+    Cc, oreps = oracle.kmeans_compute_clusters(X, frm, s, k, iters, seed)
+    assert np.array_equal(bits(km.centroids), bits(Cc))
+    assert len(reps) == len(oreps)
+    for r, o in zip(reps, oreps):
+        assert (r.num_iterations, r.converged, r.step_count) == (o["num_iterations"], o["converged"], o["step_count"])
+        assert np.float32(r.step_mean).view(np.uint32) == o["step_mean"].view(np.uint32)
+        assert np.float32(r.step_s).view(np.uint32) == o["step_s"].view(np.uint32)
+
+
+def test_iterate_bit_exact_and_descends(oracle, g):
+    X = _clustered(21, 3000, 10)
+    dm = g.DeviceMatrix.from_host(X)
+    v = g.Vectors(dm, 0, 10)
+    k0 = g.KMeans.init(6, v)
+    cur_o, _ = oracle.kmeans_init(X, 0, 10, 6, 0)
+    cur = k0
+    for iters in (1, 3, 7):
+        cur = cur.iterate(v, iters)
+        cur_o = oracle.kmeans_iterate(X, 0, 10, cur_o, iters)
+        assert np.array_equal(bits(cur.centroids), bits(cur_o))
+
+
+def test_degenerate_start_not_stuck(oracle, g):       # KMeansSpec.scala:59-72 on the GPU path
+    X = _clustered(33, 1500, 5)
+    v = g.Vectors(g.DeviceMatrix.from_host(X), 0, 5)
+    a0 = np.zeros(1500, np.int32)
+    k0 = g.KMeans.from_assignment(6, 5, v, a0)
+    k1 = k0.iterate(v, 1)
+    a1 = k1.assign(v)
+    e0 = oracle.kmeans_from_assignment(X, 0, 5, 6, a0)
+    e1 = oracle.kmeans_iterate(X, 0, 5, e0, 1)
+    assert np.array_equal(bits(k1.centroids), bits(e1))
+    assert np.array_equal(a1, oracle.kmeans_assign(X, 0, 5, e1, 0))
+
+
+@pytest.mark.parametrize("n,d,m,k,iters", [(2000, 16, 4, 16, 10), (20000, 32, 4, 256, 4), (3000, 50, 7, 20, 6),
+                                           (1500, 10, 10, 3, 5), (1200, 6, 2, 1, 2)])
+def test_pq_train_encode_bit_exact(oracle, g, n, d, m, k, iters):
+    X = _clustered(n, n, d)
+    dm = g.DeviceMatrix.from_host(X)
+    pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, iters))
+    cents, _, _ = oracle.pq_train(X, m, k, iters)
+    assert np.array_equal(bits(pq.flat_centroids()), bits(cents))
+    enc = pq.encode(dm)
+    idx = oracle.pq_encode(X, m, k, cents)
+    assert np.array_equal(enc.indices(), idx)
+    w = oracle.coder_width_for_clusters(k)
+    for j in range(m):
+        assert np.array_equal(enc.encodings[j], oracle.coder_build(w, idx[j]))
+    # decode(encode) idempotent (ProductQuantizerSpec.scala:15-26)
+    dec = pq.decode(enc)
+    assert np.array_equal(bits(dec.data), bits(oracle.pq_decode(idx, d, k, cents)))
+
+
+def test_index_sorted_end_to_end(oracle, g):
+    """Index.sorted + batchQuery: GPU train -> encode -> scan equals the oracle end to end."""
+    n, d, m, k = 30000, 64, 8, 256
+    X = oracle.synth(n, d, 1, 7, 50)
+    dm = g.DeviceMatrix.synthetic(n, d, 1, 7, 50)
+    pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, 3))
+    si = g.Index.sorted(dm, pq)
+    Q = X[[5, 77, 1234, 29999]]
+    res = si.batch_query(10, Q)
+    cents, _, _ = oracle.pq_train(X, m, k, 3)
+    idx = oracle.pq_encode(X, m, k, cents)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, 10)
+    for q, r in enumerate(res):
+        assert np.array_equal(bits(r.distances), bits(od[q]))
+        if r.flags == 0:
+            assert r.rows.tolist() == oi[q].tolist()
