@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): queries/sec + recall@10 on a 10M x 128 PQ(m=16,k=256)
+index, batch = 1024, K = 10, row-sharded over N GPUs (one process per GPU).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one batch of 1024 queries through the hot path with everything resident in HBM:
+distance-table build -> ADC scan of this rank's row shard + wavefront top-k -> (N > 1: RCCL
+all-gather of the per-shard partial top-(K+1) lists) -> merge.  Index build (synthetic data,
+PQ training, encoding) happens once, untimed, through the same library.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--clusters", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--knn", type=int, default=10)
+    ap.add_argument("--train-iters", type=int, default=10)
+    ap.add_argument("--data-kind", type=int, default=3, help="0 iid, 1 clustered, 2 uniform, 3 overlapping clusters")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gulon_amd as g
+    from gulon_amd import native as N
+    from gulon_amd.recall import recall_at_k, sample_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    N.check(N.lib().gulon_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    L = N.lib()
+    n, d, m, k, B, K = args.n, args.d, args.m, args.clusters, args.batch, args.knn
+
+    # ---- untimed build: synthetic clustered data -> PQ train -> encode (all on the GPU) -----
+    t0 = time.perf_counter()
+    dm = g.DeviceMatrix.synthetic(n, d, args.data_kind, 1234, 1000)
+    t1 = time.perf_counter()
+    pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, args.train_iters))
+    t2 = time.perf_counter()
+    enc = pq.encode(dm)
+    t3 = time.perf_counter()
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    nloc = hi - lo
+    coder = pq.coder_factory(nloc)
+    if coder.width == 8:
+        shard = g.EncodedMatrix(coder, [e[lo:hi] for e in enc.encodings])
+    else:
+        idx_all = enc.indices()
+        shard = g.EncodedMatrix(coder, [coder.build_code(idx_all[j, lo:hi]) for j in range(m)])
+    index = g.PQIndex(pq, shard, row_base=lo)
+    build_s = dict(synth=t1 - t0, train=t2 - t1, encode=t3 - t2)
+
+    # ---- queries: B dataset rows drawn with java.util.Random(0) (Tests.scala:76-87) --------
+    qrows = sample_rows(n, B, 0)
+    Qh = dm.get_rows(qrows)
+    Q = torch.from_numpy(Qh).to(dev)
+    out_idx = torch.empty((B, K), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    out_flg = torch.empty((B,), dtype=torch.int32, device=dev)
+    part_v = torch.empty((B, K + 1), dtype=torch.float32, device=dev)
+    part_i = torch.empty((B, K + 1), dtype=torch.int32, device=dev)
+    all_v = torch.empty((world, B, K + 1), dtype=torch.float32, device=dev)
+    all_i = torch.empty((world, B, K + 1), dtype=torch.int32, device=dev)
+
+    def stream_ptr():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        if world == 1:
+            N.check(L.gulon_index_batch_query_dev(index._h, Q.data_ptr(), B, K, 0, nloc, out_idx.data_ptr(),
+                                                  out_dist.data_ptr(), out_cnt.data_ptr(), out_flg.data_ptr(),
+                                                  stream_ptr()))
+        else:
+            N.check(L.gulon_index_scan_partial_dev(index._h, Q.data_ptr(), B, K, 0, nloc, part_v.data_ptr(),
+                                                   part_i.data_ptr(), stream_ptr()))
+            dist.all_gather_into_tensor(all_v, part_v)
+            dist.all_gather_into_tensor(all_i, part_i)
+            N.check(L.gulon_topk_merge_dev(all_v.data_ptr(), all_i.data_ptr(), world, 0, B, K, out_idx.data_ptr(),
+                                           out_dist.data_ptr(), out_cnt.data_ptr(), out_flg.data_ptr(), stream_ptr()))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    N.check(L.gulon_index_profile(index._h, 1))
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_total, launches = C.c_double(0), C.c_int32(0)
+    N.check(L.gulon_index_profile_read(index._h, C.byref(ms_total), C.byref(launches)))
+    N.check(L.gulon_index_profile(index._h, 0))
+    scan_ms = ms_total.value / max(launches.value, 1)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = B * args.steps / elapsed
+    alg_bytes = float(B) * nloc * m                       # n*m code bytes per query
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf)).get(f"n{nloc}_m{m}_B{B}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:
+            traffic = None
+
+    res_idx = out_idx.cpu().numpy()
+    res_cnt = out_cnt.cpu().numpy()
+    res_dist = out_dist.cpu().numpy()
+    res_flg = out_flg.cpu().numpy()
+
+    result = {
+        "metric": "queries_per_sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n}x{d} synthetic (kind {args.data_kind}, 1000 centres, seed 1234), PQ(m={m},k={k}) flat ADC scan, batch={B}, K={K}, "
+                               f"rows sharded over {world} GPU(s)", "n": n, "d": d, "m": m, "k": k, "batch": B,
+                   "knn": K, "train_max_iterations": args.train_iters, "rows_per_gpu": nloc},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "scan_kernel",
+                     "kernel_ms": scan_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "build_seconds": build_s,
+    }
+
+    if rank == 0:
+        if not args.no_recall:
+            t = time.perf_counter()
+            mean, sd = recall_at_k(dm, Qh, K, res_idx, res_cnt)
+            result["recall_at_10" if K == 10 else f"recall_at_{K}"] = mean
+            result["recall_sd"] = sd
+            result["recall_seconds"] = time.perf_counter() - t
+            result["tie_flagged_queries"] = int((res_flg != 0).sum())
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle                      # CPU baseline leg only (the checker, timed)
+            codes_h = np.stack(enc.encodings) if coder.width == 8 else None
+            cents = pq.flat_centroids()
+            if codes_h is not None:
+                cq, spent, t_cpu, n_q = 1, 0.0, 0.0, 0
+                oi = od = None
+                ois, ods = [], []
+                while spent < args.cpu_seconds and n_q < B:
+                    cq = min(cq, B - n_q)
+                    t = time.perf_counter()
+                    a, b_, _ = oracle.pq_batch_query(codes_h, d, k, cents, Qh[n_q:n_q + cq], K)
+                    dt = time.perf_counter() - t
+                    ois.append(a); ods.append(b_)
+                    spent += dt; t_cpu += dt; n_q += cq
+                    per_q = t_cpu / n_q
+                    cq = max(1, min(int((args.cpu_seconds - spent) / per_q), 64))
+                    if args.cpu_seconds - spent < per_q:
+                        break
+                oi, od = np.concatenate(ois), np.concatenate(ods)
+                same_d = bool(np.array_equal(od.view(np.uint32), res_dist[:n_q].view(np.uint32)))
+                same_i = bool(all(res_flg[q] != 0 or np.array_equal(oi[q], res_idx[q]) for q in range(n_q)))
+                result["cpu_baseline"] = {
+                    "value": n_q / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
+                    "sample": f"first {n_q} of the {B} queries over all {n} rows, single thread, "
+                              f"4096-row blocks (Index.scala:424); C restatement of Gulon's JVM algorithm"}
+                result["parity_vs_oracle"] = {"queries": n_q, "distances_bit_exact": same_d, "ids_equal": same_i}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

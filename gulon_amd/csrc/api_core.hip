@@ -47,8 +47,14 @@ __global__ void synth_fill(float *__restrict__ X, long long total, int d, int ki
   else {
     uint64_t ce = mix64(mix64(seed ^ 0x5851F42D4C957F2DULL) + row) % (uint64_t)ncentres;
     uint64_t cidx = ce * (uint64_t)d + c;
-    float centre = synth_uniform(seed, 2, cidx) * 10.0f - 5.0f;
-    float scale = synth_uniform(seed, 3, cidx) * 0.9f + 0.1f;
+    float centre, scale;
+    if (kind == 1) {
+      centre = synth_uniform(seed, 2, cidx) * 10.0f - 5.0f;
+      scale = synth_uniform(seed, 3, cidx) * 0.9f + 0.1f;
+    } else {
+      centre = synth_uniform(seed, 2, cidx) * 4.0f - 2.0f;
+      scale = synth_uniform(seed, 3, cidx) + 0.5f;
+    }
     float g = synth_gauss(seed, 1, idx);
     v = centre + g * scale;
   }
@@ -226,7 +232,7 @@ GULON_API int32_t gulon_dataset_create_synth(int32_t n, int32_t d, int32_t kind,
   return guarded([&] {
     GULON_REQUIRE(out != nullptr, "out is null");
     *out = nullptr;
-    GULON_REQUIRE(n >= 0 && d >= 1 && kind >= 0 && kind <= 2 && (kind != 1 || ncentres >= 1), "bad synth arguments");
+    GULON_REQUIRE(n >= 0 && d >= 1 && kind >= 0 && kind <= 3 && ((kind != 1 && kind != 3) || ncentres >= 1), "bad synth arguments");
     std::unique_ptr<gulon_dataset> ds(new gulon_dataset());
     ds->n = n; ds->d = d;
     long long total = (long long)n * d;

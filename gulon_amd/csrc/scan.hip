@@ -345,7 +345,13 @@ struct gulon_index {
   DevBuf<float> stage_q;
   DevBuf<int> stage_oi, stage_oc, stage_of;
   DevBuf<float> stage_od;
+  // optional hipEvent bracketing of the scan kernel (bench.py roofline line)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::mutex mu;
+  ~gulon_index() {
+    for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
 };
 
 namespace {
@@ -435,7 +441,17 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
                        ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, ix->tables.p);
     HIP_CHECK(hipGetLastError());
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->profile) {
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, st));
+  }
   launch_scan(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
+  if (ix->profile) {
+    HIP_CHECK(hipEventRecord(e1, st));
+    ix->events.emplace_back(e0, e1);
+  }
   launch_merge(final_out, ix->part_v.p, ix->part_i.p, nchunks, (long long)keff, (long long)nchunks * keff, B, K, d_oi,
                d_od, d_oc, d_of, d_pv, d_pi, st);
 }
@@ -561,14 +577,42 @@ GULON_API int32_t gulon_index_batch_query(gulon_index *idx, const float *queries
   });
 }
 
-GULON_API int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists, int32_t b,
-                                       int32_t k_nn, int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
-                                       int32_t *d_out_flags, void *stream) {
+GULON_API int32_t gulon_index_profile(gulon_index *idx, int32_t enable) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (auto &e : idx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    idx->events.clear();
+    idx->profile = enable != 0;
+  });
+}
+
+GULON_API int32_t gulon_index_profile_read(gulon_index *idx, double *scan_ms_total, int32_t *launches) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    double tot = 0;
+    for (auto &e : idx->events) {
+      HIP_CHECK(hipEventSynchronize(e.second));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e.first, e.second));
+      tot += ms;
+    }
+    if (scan_ms_total) *scan_ms_total = tot;
+    if (launches) *launches = (int32_t)idx->events.size();
+  });
+}
+
+GULON_API int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists,
+                                       int64_t list_stride, int32_t b, int32_t k_nn, int32_t *d_out_idx,
+                                       float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream) {
   return guarded([&] {
     GULON_REQUIRE(lists >= 1 && b >= 0 && k_nn >= 1, "bad merge shape");
     GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
     int keff = k_nn + 1;
-    launch_merge(true, d_part_dist, d_part_idx, lists, (long long)b * keff, (long long)keff, b, k_nn, d_out_idx,
+    GULON_REQUIRE(list_stride == 0 || list_stride >= (long long)b * keff, "list_stride too small");
+    launch_merge(true, d_part_dist, d_part_idx, lists, list_stride ? (long long)list_stride : (long long)b * keff,
+                 (long long)keff, b, k_nn, d_out_idx,
                  d_out_dist, d_out_count, d_out_flags, nullptr, nullptr, (hipStream_t)stream);
   });
 }

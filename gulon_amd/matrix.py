@@ -48,7 +48,7 @@ class DeviceMatrix:
 
     @classmethod
     def synthetic(cls, n, d, kind, seed, ncentres=1000):
-        """kind: 0 iid N(0,1), 1 clustered, 2 U[0,1) -- bit-identical to oracle.synth."""
+        """kind: 0 iid N(0,1), 1 clustered, 2 U[0,1), 3 overlapping clusters -- bit-identical to oracle.synth."""
         h = C.c_void_p()
         N.check(N.lib().gulon_dataset_create_synth(n, d, kind, seed, ncentres, C.byref(h)))
         return cls(h, n, d)

@@ -90,7 +90,7 @@ int32_t gulon_coder_unpack(int32_t width, const uint8_t *code, int32_t length, i
 /* Copies an n x d row-major host matrix to HBM (Matrix.scala:3). */
 int32_t gulon_dataset_create(const float *x_host, int32_t n, int32_t d, gulon_dataset **out);
 /* Synthetic data generated on the device, bit-identical to the CPU test
- * generator: kind 0 iid N(0,1)~Irwin-Hall, 1 clustered, 2 U[0,1). */
+ * generator: kind 0 iid N(0,1)~Irwin-Hall, 1 clustered, 2 U[0,1), 3 overlapping clusters. */
 int32_t gulon_dataset_create_synth(int32_t n, int32_t d, int32_t kind, uint64_t seed,
                                    int32_t ncentres, gulon_dataset **out);
 int32_t gulon_dataset_destroy(gulon_dataset *ds);
@@ -168,12 +168,18 @@ int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, in
 int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
                                      int32_t from, int32_t until, float *d_part_dist,
                                      int32_t *d_part_idx, void *stream);
+/* Kernel timing for the roofline line of bench.py: when enabled, every scan-kernel
+ * launch of this index is bracketed by hipEvents on the launch stream;
+ * gulon_index_profile_read synchronises them and returns the summed duration. */
+int32_t gulon_index_profile(gulon_index *idx, int32_t enable);
+int32_t gulon_index_profile_read(gulon_index *idx, double *scan_ms_total, int32_t *launches);
 /* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
  * the deterministic (distance, row id) order: merges `lists` partial lists per
- * query, laid out [lists][B][K+1], into the final K. */
+ * query, laid out [lists][B][K+1], into the final K.  list_stride = elements
+ * between consecutive lists (0 = B*(K+1), i.e. dense). */
 int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists,
-                             int32_t b, int32_t k_nn, int32_t *d_out_idx, float *d_out_dist,
-                             int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+                             int64_t list_stride, int32_t b, int32_t k_nn, int32_t *d_out_idx,
+                             float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);
 /* host-pointer convenience form of the same merge */
 int32_t gulon_topk_merge(const float *part_dist, const int32_t *part_idx, int32_t lists, int32_t b,
                          int32_t k_nn, int32_t *out_idx, float *out_dist, int32_t *out_count,

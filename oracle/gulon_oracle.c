@@ -669,7 +669,9 @@ GO_API float go_synth_gauss(uint64_t seed, uint64_t stream, uint64_t idx) {
   return acc - 6.0f;
 }
 /* kind 0: iid N(0,1); kind 1: clustered (ncentres centres U(-5,5), per-dim
- * scale U(0.1,1), row = centre + g*scale); kind 2: U[0,1) */
+ * scale U(0.1,1), row = centre + g*scale -- the shape of the reference's test
+ * generator, Generators.scala:18-60); kind 2: U[0,1); kind 3: overlapping
+ * clusters (centres U(-2,2), scale U(0.5,1.5)): PQ codes stay (almost) unique */
 GO_API void go_synth_fill(float *X, int64_t row0, int64_t nrows, int32_t d, int32_t kind,
                           uint64_t seed, int32_t ncentres) {
   for (int64_t r = 0; r < nrows; r++) {
@@ -682,8 +684,14 @@ GO_API void go_synth_fill(float *X, int64_t row0, int64_t nrows, int32_t d, int3
       else {
         uint64_t ce = go_mix64(go_mix64(seed ^ 0x5851F42D4C957F2DULL) + row) % (uint64_t)ncentres;
         uint64_t cidx = ce * (uint64_t)d + (uint64_t)c;
-        float centre = go_synth_uniform(seed, 2, cidx) * 10.0f - 5.0f;
-        float scale = go_synth_uniform(seed, 3, cidx) * 0.9f + 0.1f;
+        float centre, scale;
+        if (kind == 1) {
+          centre = go_synth_uniform(seed, 2, cidx) * 10.0f - 5.0f;
+          scale = go_synth_uniform(seed, 3, cidx) * 0.9f + 0.1f;
+        } else {
+          centre = go_synth_uniform(seed, 2, cidx) * 4.0f - 2.0f;
+          scale = go_synth_uniform(seed, 3, cidx) + 0.5f;
+        }
         float g = go_synth_gauss(seed, 1, idx);
         v = centre + g * scale;
       }

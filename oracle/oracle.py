@@ -370,7 +370,7 @@ def recall(X, Q, K, ann_idx, ann_count, exact_dist, exact_count):
 
 
 def synth(n, d, kind, seed, ncentres=1000, row0=0):
-    """kind: 0 iid N(0,1), 1 clustered, 2 U[0,1).  Bit-identical to the HIP generator."""
+    """kind: 0 iid N(0,1), 1 clustered, 2 U[0,1), 3 overlapping clusters.  Bit-identical to the HIP generator."""
     X = np.zeros((n, d), np.float32)
     lib().go_synth_fill(X, row0, n, d, kind, seed, ncentres)
     return X

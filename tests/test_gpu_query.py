@@ -154,7 +154,7 @@ def test_sharded_partials_merge_equals_full(oracle, g):
 
 
 def test_synthetic_data_matches_oracle(oracle, g):
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 3):
         dm = g.DeviceMatrix.synthetic(3000, 50, kind, 1234, 17)
         X = dm.to_host()
         assert np.array_equal(bits(X), bits(oracle.synth(3000, 50, kind, 1234, 17)))
