@@ -49,6 +49,7 @@ def main():
     import gulon_amd as g
     from gulon_amd import native as N
     from gulon_amd.recall import recall_at_k, sample_rows
+    from gulon_amd.sharded import HipEngine, ShardedIndex, local_shard, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -75,45 +76,24 @@ def main():
     t2 = time.perf_counter()
     enc = pq.encode(dm)
     t3 = time.perf_counter()
-    lo, hi = n * rank // world, n * (rank + 1) // world
+    lo, hi = shard_bounds(n, world, rank)
     nloc = hi - lo
     coder = pq.coder_factory(nloc)
-    if coder.width == 8:
-        shard = g.EncodedMatrix(coder, [e[lo:hi] for e in enc.encodings])
-    else:
-        idx_all = enc.indices()
-        shard = g.EncodedMatrix(coder, [coder.build_code(idx_all[j, lo:hi]) for j in range(m)])
-    index = g.PQIndex(pq, shard, row_base=lo)
+    engine = HipEngine(pq, local_shard(pq, enc, lo, hi), lo, dev)
+    sharded = ShardedIndex(engine, n, rank, world, dist)
+    index = engine.index
     build_s = dict(synth=t1 - t0, train=t2 - t1, encode=t3 - t2)
 
     # ---- queries: B dataset rows drawn with java.util.Random(0) (Tests.scala:76-87) --------
     qrows = sample_rows(n, B, 0)
     Qh = dm.get_rows(qrows)
     Q = torch.from_numpy(Qh).to(dev)
-    out_idx = torch.empty((B, K), dtype=torch.int32, device=dev)
-    out_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
-    out_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
-    out_flg = torch.empty((B,), dtype=torch.int32, device=dev)
-    part_v = torch.empty((B, K + 1), dtype=torch.float32, device=dev)
-    part_i = torch.empty((B, K + 1), dtype=torch.int32, device=dev)
-    all_v = torch.empty((world, B, K + 1), dtype=torch.float32, device=dev)
-    all_i = torch.empty((world, B, K + 1), dtype=torch.int32, device=dev)
-
-    def stream_ptr():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        if world == 1:
-            N.check(L.gulon_index_batch_query_dev(index._h, Q.data_ptr(), B, K, 0, nloc, out_idx.data_ptr(),
-                                                  out_dist.data_ptr(), out_cnt.data_ptr(), out_flg.data_ptr(),
-                                                  stream_ptr()))
-        else:
-            N.check(L.gulon_index_scan_partial_dev(index._h, Q.data_ptr(), B, K, 0, nloc, part_v.data_ptr(),
-                                                   part_i.data_ptr(), stream_ptr()))
-            dist.all_gather_into_tensor(all_v, part_v)
-            dist.all_gather_into_tensor(all_i, part_i)
-            N.check(L.gulon_topk_merge_dev(all_v.data_ptr(), all_i.data_ptr(), world, 0, B, K, out_idx.data_ptr(),
-                                           out_dist.data_ptr(), out_cnt.data_ptr(), out_flg.data_ptr(), stream_ptr()))
+        # table build -> local ADC scan + top-k -> (world > 1: all-gather partial lists) -> merge
+        return sharded.batch_query_dev(Q, B, K)
+
+    out_idx, out_dist, out_cnt, out_flg = step()
 
     def barrier():
         if dist is not None:

@@ -159,6 +159,17 @@ struct JRandom {
 // (distance, row id) order otherwise -- DESIGN.md "tie rule".
 // ---------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Cross-lane moves that stay off the LDS pipe (the scan saturates it): v_readlane for a
+// wave-uniform source lane, DPP wave_shr:1 for the shift-by-one of an insertion.
+__device__ inline int readlane_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ inline float readlane_f(float x, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+__device__ inline int wave_shr1_i(int x) {   // lane i <- lane i-1 (lane 0 keeps its own value)
+  return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ inline float wave_shr1_f(float x) { return __int_as_float(wave_shr1_i(__float_as_int(x))); }
+
 struct WaveList {
   float v;   // this lane's distance
   int i;     // this lane's row id
@@ -173,13 +184,13 @@ struct WaveList {
   __device__ void insert(float cv, int cr, int keff, int lane) {
     bool before = (v < cv) || (v == cv && i < cr);
     int pos = __popcll(__ballot(before));
-    float uv = __shfl_up(v, 1);
-    int ui = __shfl_up(i, 1);
+    float uv = wave_shr1_f(v);
+    int ui = wave_shr1_i(i);
     if (lane == pos) { v = cv; i = cr; }
     else if (lane > pos) { v = uv; i = ui; }
     if (lane >= keff) { v = INFINITY; i = INT_MAX; }
-    tau = __shfl(v, keff - 1);
-    tau_i = __shfl(i, keff - 1);
+    tau = readlane_f(v, keff - 1);
+    tau_i = readlane_i(i, keff - 1);
   }
 };
 #endif

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float *__restric
       while (mk) {
         int l = __ffsll((long long)mk) - 1;
         mk &= mk - 1;
-        float cv = __shfl(acc[q], l);
+        float cv = readlane_f(acc[q], l);
         int cr = base + wave * 64 + l;
         if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
           wl[q].insert(cv, cr, keff, lane);

@@ -122,11 +122,12 @@ __device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
   return (x >> (8 * (b & 3))) & 0xFFu;
 }
 
-template <int NSUB, int VEC, int THREADS>
+template <int NSUB, int VEC, int THREADS, bool PRUNE>
 __global__ __launch_bounds__(THREADS) void scan_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
     int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
-    int keff, float *__restrict__ part_v, int *__restrict__ part_i) {
+    int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
+    int prune_from) {
   constexpr int QT = 4 * NSUB;
   constexpr int NW = THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
@@ -138,6 +139,14 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   const int tile = blockIdx.x;   // query tile (fastest: tiles of one chunk run together)
   const int chunk = blockIdx.y;
   const int tab_entries = m_pad * 256;  // float4 per sub-table
+
+  // Shared pruning thresholds, as the bits of non-negative floats (so unsigned min == float
+  // min): tau_sh[q] >= the (K+1)-th smallest distance of query q over everything scanned so
+  // far by ANY wave of ANY workgroup (gtau is the cross-workgroup copy).  A row whose
+  // distance exceeds it can never be in the final top-(K+1), so it is dropped before the
+  // (expensive, wave-serial) insertion.  Only speed depends on how fresh these values are.
+  unsigned *tau_sh = reinterpret_cast<unsigned *>(lds + tau_off4);
+  if (tid < QT) tau_sh[tid] = __hip_atomic_load(&gtau[tile * QT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // stage the NSUB sub-tables of this query tile
   {
@@ -155,28 +164,61 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   const int rb1 = min(rb_end, rb0 + rb_per_chunk);
   const Word *cw = reinterpret_cast<const Word *>(codes);
 
+  // software pipeline: the first code word of the NEXT row block is in flight while this
+  // one is being looked up (global latency would otherwise idle the LDS pipe)
+  Word w_first{};
+  if (rb0 + wave < rb1) w_first = cw[((size_t)(rb0 + wave) * ng) * 64 + lane];
   for (int rb = rb0 + wave; rb < rb1; rb += NW) {
     float acc[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) acc[q] = 0.f;
 
     const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
-    Word w = p[0];
+    Word w = w_first;
+    if (rb + NW < rb1) w_first = cw[((size_t)(rb + NW) * ng) * 64 + lane];
+
+    // workgroup-shared thresholds (wave-uniform LDS reads); <= keeps exact-tie candidates
+    float tsh[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++)
+      tsh[q] = __uint_as_float(__hip_atomic_load(&tau_sh[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+
+    // Exact early termination.  Every table entry is a sum of squares (>= 0) and binary32
+    // addition of a non-negative term is monotone, so a j-ordered PARTIAL sum is a lower
+    // bound of the full distance.  Once all 64 rows x 4 queries of a sub-table are already
+    // above their thresholds, none of them can enter a top-(K+1) list and the remaining
+    // look-ups of that sub-table are skipped; rows that survive still get bit-exact sums.
+    bool live[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) live[s] = true;
+
     for (int g = 0; g < ng; g++) {
       Word wn = w;
       if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
       const float4 *tj = lds + g * VEC * 256;
 #pragma unroll
-      for (int b = 0; b < VEC; b++) {
-        uint32_t c = code_byte<VEC>(w, b);
-        const float4 *e = tj + b * 256 + c;
+      for (int seg = 0; seg < VEC / 4; seg++) {
+        if (PRUNE && g * VEC + seg * 4 >= prune_from) {
+#pragma unroll
+          for (int s = 0; s < NSUB; s++)
+            if (live[s])
+              live[s] = __ballot(acc[4 * s + 0] <= tsh[4 * s + 0] || acc[4 * s + 1] <= tsh[4 * s + 1] ||
+                                 acc[4 * s + 2] <= tsh[4 * s + 2] || acc[4 * s + 3] <= tsh[4 * s + 3]) != 0ull;
+        }
 #pragma unroll
         for (int s = 0; s < NSUB; s++) {
-          float4 t = e[s * tab_entries];
-          acc[4 * s + 0] += t.x;
-          acc[4 * s + 1] += t.y;
-          acc[4 * s + 2] += t.z;
-          acc[4 * s + 3] += t.w;
+          if (!PRUNE || live[s]) {
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+              const int b = seg * 4 + bb;
+              uint32_t c = code_byte<VEC>(w, b);
+              float4 t = tj[b * 256 + c + s * tab_entries];
+              acc[4 * s + 0] += t.x;
+              acc[4 * s + 1] += t.y;
+              acc[4 * s + 2] += t.z;
+              acc[4 * s + 3] += t.w;
+            }
+          }
         }
       }
       w = wn;
@@ -184,13 +226,11 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
 
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
-    unsigned long long vmask = __ballot(valid);
     unsigned long long masks[QT];
     unsigned long long any = 0;
 #pragma unroll
     for (int q = 0; q < QT; q++) {
-      unsigned long long mk = __ballot(valid && acc[q] < wl[q].tau);
-      if (cnt[q] < keff) mk = vmask;  // list not full yet: everything enters (incl. +inf)
+      unsigned long long mk = (!PRUNE || live[q / 4]) ? __ballot(valid && acc[q] <= tsh[q]) : 0ull;
       masks[q] = mk;
       any |= mk;
     }
@@ -201,14 +241,27 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
         while (mk) {
           int l = __ffsll((long long)mk) - 1;
           mk &= mk - 1;
-          float cv = __shfl(acc[q], l);
+          float cv = readlane_f(acc[q], l);
           int cr = rb * 64 + l + row_base;
           if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
             wl[q].insert(cv, cr, keff, lane);
             if (cnt[q] < keff) cnt[q]++;
+            if (wl[q].tau < tsh[q]) {   // this wave's list is full and tighter: publish
+              tsh[q] = wl[q].tau;
+              if (lane == 0)
+                __hip_atomic_fetch_min(&tau_sh[q], __float_as_uint(wl[q].tau), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
       }
+    }
+    // every 32 row blocks one wave trades thresholds with the other workgroups of this tile
+    if (wave == 0 && (((rb - rb0) / NW) & 31) == 31 && lane < QT) {
+      unsigned mine = __hip_atomic_load(&tau_sh[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      unsigned old = __hip_atomic_fetch_min(&gtau[tile * QT + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old < mine)
+        __hip_atomic_fetch_min(&tau_sh[lane], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 
@@ -238,6 +291,9 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
       part_v[o] = out.v;
       part_i[o] = out.i;
     }
+    if (lane == 0 && out.tau < INFINITY)
+      __hip_atomic_fetch_min(&gtau[tile * QT + q], __float_as_uint(out.tau), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -273,8 +329,8 @@ __global__ __launch_bounds__(64) void merge_lists(const float *__restrict__ in_v
     while (mk) {
       int l = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
-      float v = __shfl(cv, l);
-      int r = __shfl(cr, l);
+      float v = readlane_f(cv, l);
+      int r = readlane_i(cr, l);
       if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
     }
   }
@@ -342,6 +398,7 @@ struct gulon_index {
   DevBuf<float> tables;
   DevBuf<float> part_v;
   DevBuf<int> part_i;
+  DevBuf<unsigned> gtau;   // per-query cross-workgroup pruning thresholds (float bits)
   DevBuf<float> stage_q;
   DevBuf<int> stage_oi, stage_oc, stage_of;
   DevBuf<float> stage_od;
@@ -356,27 +413,62 @@ struct gulon_index {
 
 namespace {
 
-constexpr int SCAN_THREADS = 512;
 constexpr size_t LDS_BUDGET = 144 * 1024;
 
-template <int NSUB, int VEC>
-void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
+// launch shape knobs (environment overrides are for tuning experiments only)
+struct ScanTuning {
+  int threads = 1024;       // workgroup size: 512 or 1024 (16 waves hide the pruning checkpoints' LDS drain)
+  int target_blocks = 4096; // workgroups per launch aimed for
+  int prune = 1;            // exact early termination on/off
+  int prune_from = -1;      // first quantizer index with a pruning checkpoint (-1: m_pad/2)
+  ScanTuning() {
+    if (const char *e = getenv("GULON_SCAN_THREADS")) { int v = atoi(e); if (v == 512 || v == 1024) threads = v; }
+    if (const char *e = getenv("GULON_SCAN_BLOCKS")) { int v = atoi(e); if (v >= 1) target_blocks = v; }
+    if (const char *e = getenv("GULON_SCAN_PRUNE")) prune = atoi(e) != 0;
+    if (const char *e = getenv("GULON_SCAN_PRUNE_FROM")) prune_from = atoi(e);
+  }
+};
+static const ScanTuning &tuning() { static ScanTuning t; return t; }
+
+template <int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
+void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
                    int until, int keff, hipStream_t st) {
   size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * sizeof(float4);
   size_t merge_bytes = (size_t)4 * NSUB * (SCAN_THREADS / 64) * 64 * 8;
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
-  auto kern = scan_kernel<NSUB, VEC, SCAN_THREADS>;
+  const int tau_off4 = (int)(lds_bytes / sizeof(float4));   // shared thresholds live after tables/merge area
+  lds_bytes += 64;
+  int prune_from = tuning().prune_from >= 0 ? tuning().prune_from : ix->m_pad / 2;
+  if (prune_from < 4) prune_from = 4;
+  auto kern = scan_kernel<NSUB, VEC, SCAN_THREADS, PRUNE>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, rb_end,
-                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p);
+                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from);
   HIP_CHECK(hipGetLastError());
+}
+
+template <int NSUB, int VEC, int SCAN_THREADS>
+void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
+                   int until, int keff, hipStream_t st) {
+  if (tuning().prune)
+    launch_scan_p<NSUB, VEC, SCAN_THREADS, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until,
+                                                 keff, st);
+  else
+    launch_scan_p<NSUB, VEC, SCAN_THREADS, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until,
+                                                  keff, st);
 }
 
 void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
                  int until, int keff, hipStream_t st) {
-#define GO(NS, V) launch_scan_t<NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st)
+#define GO(NS, V)                                                                                              \
+  do {                                                                                                         \
+    if (tuning().threads == 1024)                                                                              \
+      launch_scan_t<NS, V, 1024>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);  \
+    else                                                                                                       \
+      launch_scan_t<NS, V, 512>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);   \
+  } while (0)
   if (ix->vec == 16) {
     if (ix->nsub == 4) GO(4, 16); else if (ix->nsub == 2) GO(2, 16); else GO(1, 16);
   } else {
@@ -421,8 +513,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     return;
   }
   // chunking: ~4096 workgroups, at least 2 row blocks per wave
-  const int NW = SCAN_THREADS / 64;
-  int want = ceil_div(4096, ntiles);
+  const int NW = tuning().threads / 64;
+  int want = ceil_div(tuning().target_blocks, ntiles);
   int max_chunks = rb_total / (2 * NW);
   if (max_chunks < 1) max_chunks = 1;
   int nchunks = want < max_chunks ? want : max_chunks;
@@ -434,6 +526,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   ix->tables.ensure((size_t)(Bp / 4) * ix->m_pad * 256 * 4);
   ix->part_v.ensure((size_t)Bp * nchunks * keff);
   ix->part_i.ensure((size_t)Bp * nchunks * keff);
+  ix->gtau.ensure((size_t)Bp);
+  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
 
   {
     long long total = (long long)(Bp / 4) * ix->m_pad * 256;

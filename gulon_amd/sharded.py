@@ -1,0 +1,109 @@
+"""Row-sharded PQIndex over the GPUs of one node: one process per GPU.
+
+The code matrix is split into `world` contiguous row ranges -- exactly the
+from/until contract of PQIndex.batchQuery (Index.scala:417-419).  Every rank
+builds the same distance tables, scans its own rows, and the per-shard partial
+top-(K+1) lists are exchanged with ONE all-gather per array (RCCL over xGMI when
+the process group is "nccl"); each rank then merges the `world` lists with
+TopKHeap.merge semantics (TopKHeap.scala:44-53, used the same way by
+Index.scala:279) under the deterministic (distance, row id) order, so the
+result does not depend on the number of shards.
+
+The compute engine is pluggable only so that the orchestration (bounds, row
+bases, gather layout) can be exercised on CPU with the gloo backend in tests;
+the shipped engine is HipEngine (libgulon_hip.so) and nothing else.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native as N
+from .product_quantizer import EncodedMatrix, ProductQuantizer
+
+
+def shard_bounds(n, world, rank):
+    """Rows [lo, hi) owned by `rank`: balanced contiguous ranges."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def local_shard(pq: ProductQuantizer, encoded: EncodedMatrix, lo, hi) -> EncodedMatrix:
+    """Slice a full EncodedMatrix (every encodings(j) covers all n rows) to rows [lo, hi)."""
+    coder = pq.coder_factory(hi - lo)
+    if coder.width == 8:
+        return EncodedMatrix(coder, [e[lo:hi] for e in encoded.encodings])
+    idx = encoded.indices()
+    return EncodedMatrix(coder, [coder.build_code(idx[j, lo:hi]) for j in range(idx.shape[0])])
+
+
+class HipEngine:
+    """Local scan + merge on this rank's GPU through the C ABI (device-resident)."""
+
+    def __init__(self, pq, shard: EncodedMatrix, row_base, device):
+        import torch
+        from .index import PQIndex
+        self.torch = torch
+        self.device = device
+        self.index = PQIndex(pq, shard, row_base=row_base)
+        self.nloc = shard.length
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def alloc(self, shape, dtype):
+        t = self.torch
+        return t.empty(shape, dtype={"f32": t.float32, "i32": t.int32}[dtype], device=self.device)
+
+    def to_device(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def query_final(self, q, b, k, oi, od, oc, of):
+        N.check(N.lib().gulon_index_batch_query_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, oi.data_ptr(),
+                                                    od.data_ptr(), oc.data_ptr(), of.data_ptr(), self._stream()))
+
+    def scan_partial(self, q, b, k, pv, pi):
+        N.check(N.lib().gulon_index_scan_partial_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, pv.data_ptr(),
+                                                     pi.data_ptr(), self._stream()))
+
+    def merge(self, all_v, all_i, lists, b, k, oi, od, oc, of):
+        N.check(N.lib().gulon_topk_merge_dev(all_v.data_ptr(), all_i.data_ptr(), lists, 0, b, k, oi.data_ptr(),
+                                             od.data_ptr(), oc.data_ptr(), of.data_ptr(), self._stream()))
+
+
+class ShardedIndex:
+    """One rank's view of the row-sharded flat index."""
+
+    def __init__(self, engine, n_total, rank=0, world=1, dist=None):
+        self.engine = engine
+        self.n_total, self.rank, self.world, self.dist = n_total, rank, world, dist
+        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self._bufs = {}
+
+    def _buffers(self, b, k):
+        key = (b, k)
+        if key not in self._bufs:
+            e = self.engine
+            self._bufs[key] = dict(
+                oi=e.alloc((b, k), "i32"), od=e.alloc((b, k), "f32"), oc=e.alloc((b,), "i32"),
+                of=e.alloc((b,), "i32"), pv=e.alloc((b, k + 1), "f32"), pi=e.alloc((b, k + 1), "i32"),
+                # gathered lists, rank-major: [world*B][K+1] == [world][B][K+1]
+                av=e.alloc((self.world * b, k + 1), "f32"), ai=e.alloc((self.world * b, k + 1), "i32"))
+        return self._bufs[key]
+
+    def batch_query_dev(self, q, b, k):
+        """Enqueue one batch; returns the (device) output tensors idx, dist, count, flags."""
+        u = self._buffers(b, k)
+        if self.world == 1:
+            self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
+        else:
+            self.engine.scan_partial(q, b, k, u["pv"], u["pi"])
+            self.dist.all_gather_into_tensor(u["av"], u["pv"])
+            self.dist.all_gather_into_tensor(u["ai"], u["pi"])
+            self.engine.merge(u["av"], u["ai"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
+        return u["oi"], u["od"], u["oc"], u["of"]
+
+    def batch_query(self, k, queries):
+        """Host convenience: numpy in, numpy out (idx [B][K], dist, count, flags)."""
+        q = N.f32(queries)
+        b = q.shape[0]
+        oi, od, oc, of = self.batch_query_dev(self.engine.to_device(q), b, k)
+        return tuple(t.cpu().numpy() for t in (oi, od, oc, of))
