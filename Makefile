@@ -8,11 +8,14 @@ OBJDIR = build/obj
 LIB = gulon_amd/lib/libgulon_hip.so
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
            -fvisibility=hidden -Wall -Wno-unused-function -Iinclude
-SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip
+SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip $(CSRC)/kmeans_mfma.hip
 OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.h
 
 all: $(LIB) oracle
+
+# MFMA results are consumed by VALU/permlane code: keep accumulators in VGPRs (no v_accvgpr moves)
+$(OBJDIR)/kmeans_mfma.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)

@@ -225,7 +225,14 @@ __global__ void count_mismatch(const int *__restrict__ a, const int *__restrict_
                                unsigned *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool diff = i < n && a[i] != b[i];
-  if (__ballot(diff) && (threadIdx.x & 63) == 0) atomicOr(out, 1u);
+  // plain store of a constant: no atomic needed, and no contention when every wave differs
+  if (__ballot(diff) && (threadIdx.x & 63) == 0) *out = 1u;
+}
+
+__global__ void scatter_ties(const int *__restrict__ rows, int nrows, const unsigned *__restrict__ ties,
+                             unsigned *__restrict__ dense) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nrows) dense[rows[t]] = ties[rows[t]];
 }
 
 __global__ void narrow_assign_u8(const int *__restrict__ a, long long n, uint8_t *__restrict__ out) {
@@ -365,16 +372,34 @@ void KmeansWorkspace::ensure(int n, int k, int s) {
 // KMeans.assign / parAssign on device arrays.  d_assign is written only where a
 // centroid won (caller initialises it).  rng_batch <= 0: one stream over all rows.
 void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
-                       int rng_batch, int *d_assign, hipStream_t st) {
+                       int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps) {
   if (n <= 0) return;
   ws.ensure(n, k, s);
   const int smax = pick_smax(s);
   hipLaunchKernelGGL(prep_centroids, dim3(ceil_div(k, 64)), dim3(64), 0, st, dC, k, s, smax, ws.cpad.p, ws.off.p);
   HIP_CHECK(hipMemsetAsync(ws.tie_total.p, 0, sizeof(unsigned long long), st));
-  const int grid = ceil_div(n, 256);
+
+  // stage 1 (optional): MFMA filter decides every row whose scan is unambiguous
+  const int *rows = nullptr;
+  int nrows = n;
+  const bool filtered = ps != nullptr && mfma_assign_supported(s, k);
+  if (filtered) {
+    assign_mfma_filter(ws, *ps, dC, k, d_assign, st);
+    unsigned nf = 0;
+    HIP_CHECK(hipMemcpyAsync(&nf, ws.flag_count.p, sizeof(nf), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    ws.last_flagged = nf;
+    ws.last_draws = 0;
+    if (nf == 0) return;
+    rows = ws.flag_rows.p;
+    nrows = (int)nf;
+  }
+
+  // stage 2: exact VALU scan (all rows, or only the flagged ones)
+  const int grid = ceil_div(nrows, 256);
 #define AE(S)                                                                                                    \
   hipLaunchKernelGGL(assign_exact<S>, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, ws.off.p, k, \
-                     (const int *)nullptr, n, d_assign, ws.ties.p, ws.tie_total.p)
+                     rows, nrows, d_assign, ws.ties.p, ws.tie_total.p)
   switch (smax) {
     case 4: AE(4); break;
     case 8: AE(8); break;
@@ -384,7 +409,7 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
     case 128: AE(128); break;
     default:
       hipLaunchKernelGGL(assign_exact_generic, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax,
-                         ws.off.p, k, (const int *)nullptr, n, d_assign, ws.ties.p, ws.tie_total.p);
+                         ws.off.p, k, rows, nrows, d_assign, ws.ties.p, ws.tie_total.p);
   }
 #undef AE
   HIP_CHECK(hipGetLastError());
@@ -393,6 +418,12 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
   HIP_CHECK(hipStreamSynchronize(st));
   ws.last_draws = total;
   if (total == 0) return;
+  if (filtered) {
+    // draw counts exist only for the flagged rows: build the dense per-row array (0 elsewhere)
+    HIP_CHECK(hipMemsetAsync(ws.local.p, 0, sizeof(unsigned) * (size_t)n, st));
+    hipLaunchKernelGGL(scatter_ties, dim3(grid), dim3(256), 0, st, rows, nrows, ws.ties.p, ws.local.p);
+    HIP_CHECK(hipMemcpyAsync(ws.ties.p, ws.local.p, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  }
   // place every drawing row in its RNG stream and replay it
   const int seg_len = rng_batch > 0 ? rng_batch : n;
   const int nseg = ceil_div(n, seg_len);
@@ -402,7 +433,7 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
   hipLaunchKernelGGL(tie_block_sums, dim3(bps, nseg), dim3(1024), 0, st, ws.ties.p, n, seg_len, bps, ws.local.p,
                      ws.block_tot.p);
   hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, st, ws.block_tot.p, bps, ws.block_off.p);
-  hipLaunchKernelGGL(assign_resolve<0>, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax, ws.off.p,
+  hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax, ws.off.p,
                      k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, d_assign);
   HIP_CHECK(hipGetLastError());
 }
@@ -468,6 +499,8 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     DevBuf<float> c_prev, c_next;
     DevBuf<int> a_prev, a_next;
     std::vector<float> h_prev, h_next;
+    PackedSlice packed;      // MFMA-ready copy of this problem's column slice
+    bool use_mfma = false;
     bool done = false;
     int nrep = 0;
   };
@@ -492,7 +525,10 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
                        d_rows.p, k, pr.c_prev.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, st));
-    kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_prev.p, k, 25000, pr.a_prev.p, st);
+    pr.use_mfma = mfma_assign_supported(s, k);
+    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, st);
+    kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_prev.p, k, 25000, pr.a_prev.p, st,
+                      pr.use_mfma ? &pr.packed : nullptr);
     pr.c_prev.download(pr.h_prev.data(), (size_t)k * s, st);
     push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
   }
@@ -509,7 +545,8 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
       const int s = sdim[p];
       kmeans_update_dev(ws, dX, n, ld, from[p], s, k, pr.a_prev.p, pr.c_next.p, st);
       HIP_CHECK(hipMemsetAsync(pr.a_next.p, 0, sizeof(int) * (size_t)n, st));   // fresh Array[Int] per parAssign
-      kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_next.p, k, 25000, pr.a_next.p, st);
+      kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_next.p, k, 25000, pr.a_next.p, st,
+                        pr.use_mfma ? &pr.packed : nullptr);
       hipLaunchKernelGGL(count_mismatch, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr.a_prev.p, pr.a_next.p, n,
                          mism.p + p);
       pr.c_next.download(pr.h_next.data(), (size_t)k * s, st);
@@ -579,7 +616,10 @@ GULON_API int32_t gulon_kmeans_assign(const gulon_dataset *ds, int32_t from, int
     KmeansWorkspace ws;
     DevBuf<float> dc; dc.upload(centroids, std::max<size_t>((size_t)k * s, 1));
     DevBuf<int> da; da.upload(assignments, ds->n);
-    kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, rng_batch, da.p, nullptr);
+    PackedSlice packed;
+    const bool mf = mfma_assign_supported(s, k);
+    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, packed, nullptr);
+    kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, rng_batch, da.p, nullptr, mf ? &packed : nullptr);
     da.download(assignments, ds->n);
     HIP_CHECK(hipDeviceSynchronize());
   });
@@ -610,8 +650,11 @@ GULON_API int32_t gulon_kmeans_iterate(const gulon_dataset *ds, int32_t from, in
     DevBuf<float> dc; dc.upload(c_in, (size_t)k * s);
     DevBuf<int> da(std::max(ds->n, 1));
     HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)std::max(ds->n, 1)));   // one array reused (KMeans.scala:101)
+    PackedSlice packed;
+    const bool mf = iters > 0 && mfma_assign_supported(s, k);
+    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, packed, nullptr);
     for (int it = 0; it < iters; it++) {
-      kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, 0, da.p, nullptr);
+      kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, 0, da.p, nullptr, mf ? &packed : nullptr);
       kmeans_update_dev(ws, ds->x.p, ds->n, ds->d, from, s, k, da.p, dc.p, nullptr);
     }
     dc.download(c_out, (size_t)k * s);
@@ -668,11 +711,14 @@ GULON_API int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k,
     DevBuf<int> da(n);
     DevBuf<uint8_t> d8(n);
     std::vector<int> h_idx;
+    PackedSlice packed;
     for (int j = 0; j < m; j++) {
       const int s = until[j] - from[j];
       dc.upload(cents + (size_t)k * from[j], (size_t)k * s);
       HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)n));
-      kmeans_assign_dev(ws, ds->x.p, n, ds->d, from[j], s, dc.p, k, 0, da.p, nullptr);   // serial assign
+      const bool mf = mfma_assign_supported(s, k);
+      if (mf) pack_slice(ds->x.p, n, ds->d, from[j], s, packed, nullptr);
+      kmeans_assign_dev(ws, ds->x.p, n, ds->d, from[j], s, dc.p, k, 0, da.p, nullptr, mf ? &packed : nullptr);   // serial assign
       uint8_t *out = codes_out + (size_t)j * bytes;
       if (width == 8) {                                                                   // Coder8: idx.toByte
         hipLaunchKernelGGL(narrow_assign_u8, dim3(ceil_div(n, 256)), dim3(256), 0, 0, da.p, (long long)n, d8.p);

@@ -6,18 +6,37 @@
 
 namespace gulon {
 
+// MFMA-ready copy of the column slice X[:, from:from+s]: [ceil(n/64)*2][T][64] floats,
+// element (tile, t, l) = X[tile*32 + (l&31)][from + 2t + (l>>5)]  (kmeans_mfma.hip)
+struct PackedSlice {
+  DevBuf<float> xq;
+  int n = 0, from = 0, s = 0, T = 0;
+};
+
 struct KmeansWorkspace {
   DevBuf<float> cpad, off;
   DevBuf<unsigned> ties, local, block_tot;
   DevBuf<unsigned long long> tie_total, block_off;
   DevBuf<unsigned> hist, count, start, mismatch;
   DevBuf<int> order;
+  // MFMA filter
+  DevBuf<float> apack, offp;
+  DevBuf<unsigned> cmax2, flag_count, flag_ties;
+  DevBuf<int> flag_rows;
   unsigned long long last_draws = 0;   // RNG draws made by the last assign (0 = no exact ties)
+  unsigned last_flagged = 0;           // rows the MFMA filter sent to the exact kernel
   void ensure(int n, int k, int s);
 };
 
+bool mfma_assign_supported(int s, int k);
+void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps, hipStream_t st);
+void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float *dC, int k, int *d_assign,
+                        hipStream_t st);
+
+// KMeans.assign / parAssign.  `ps` (nullable): packed copy of the slice => MFMA filter +
+// exact re-check of the flagged rows; without it every row takes the exact VALU kernel.
 void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
-                       int rng_batch, int *d_assign, hipStream_t st);
+                       int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps = nullptr);
 void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
                        const int *d_assign, float *dC, hipStream_t st);
 

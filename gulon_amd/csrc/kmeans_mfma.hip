@@ -1,0 +1,234 @@
+// MFMA filter for KMeans.assign (KMeans.scala:24-98) on gfx950.
+//
+// The reference computes, per row and centroid, d = offsets[c] - 2*(x . c) with an
+// unfused sequential fp32 chain and takes the argmin with strict '<' (ties draw from
+// java.util.Random).  v_mfma_f32_32x32x2_f32 computes the same quantity as an fma chain
+// (one rounding per product-add), so its value d' differs from d by at most
+//     E = (2s+1) * 2^-24 * (|c|^2 + 2 |x||c|) * (1 + o(1))
+// (Higham's gamma bounds for both chains).  The filter replays the reference's scan over
+// c = 0..k-1 on d':  if every comparison against the running minimum is decided by more
+// than 2E, the reference's scan takes exactly the same branches, draws no random bit, and
+// the MFMA argmin IS the reference's answer.  Rows with any comparison inside the 2E band
+// (including exact ties) are appended to a list and re-evaluated by the exact VALU kernel
+// (assign_exact + assign_resolve in kmeans.hip).  Output is therefore bit-identical to the
+// reference algorithm; the MFMA only decides which rows need the expensive path.
+//
+// Layout: centroid tiles are the MFMA M dimension, data rows the N dimension, the
+// sub-vector the K dimension (2 per instruction).  The data slice is pre-packed once per
+// (dataset, slice) as [n/32][T][64] so every B operand is one coalesced 256-byte load; the
+// -2*c A operands and the offsets (C-init) sit in LDS.  After the K loop two 32x32 tiles
+// are exchanged with v_permlane32_swap so that each lane owns ONE data row and sees its
+// 32 distances of the centroid block in ascending centroid order.
+#include "kmeans.hpp"
+
+namespace gulon {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// pack X[:, from:from+s] into MFMA B-operand order: out[(tile*T + t)*64 + l] =
+// X[tile*32 + (l&31)][from + 2t + (l>>5)]  (0 outside the matrix / the slice)
+__global__ void pack_slice_kernel(const float *__restrict__ X, int n, int ld, int from, int s, int T,
+                                  long long total, float *__restrict__ out) {
+  long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 >= total) return;
+  int l = (int)(t0 & 63);
+  long long tt = t0 >> 6;
+  int t = (int)(tt % T);
+  long long tile = tt / T;
+  long long row = tile * 32 + (l & 31);
+  int e = 2 * t + (l >> 5);
+  out[t0] = (row < n && e < s) ? X[(size_t)row * ld + from + e] : 0.f;
+}
+
+// A operands (-2*c), C-init offsets (+inf beyond k) and max |c|^2
+__global__ void pack_centroids_kernel(const float *__restrict__ C, const float *__restrict__ off, int k, int s, int T,
+                                      int nkb, float *__restrict__ apack, float *__restrict__ offp,
+                                      unsigned *__restrict__ cmax2_bits) {
+  int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 < nkb * T * 64) {
+    int l = t0 & 63, t = (t0 >> 6) % T, kb = (t0 >> 6) / T;
+    int c = kb * 32 + (l & 31), e = 2 * t + (l >> 5);
+    apack[t0] = (c < k && e < s) ? -2.0f * C[(size_t)c * s + e] : 0.f;
+  }
+  if (t0 < nkb * 32) {
+    float o = t0 < k ? off[t0] : INFINITY;
+    offp[t0] = o;
+    if (t0 < k && o == o && o < INFINITY) atomicMax(cmax2_bits, __float_as_uint(o));
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq, int n, long long npairs,
+                                                   const float *__restrict__ apack, const float *__restrict__ offp,
+                                                   int nkb, const unsigned *__restrict__ cmax2_bits, float errk,
+                                                   int *__restrict__ assign, int *__restrict__ flag_rows,
+                                                   unsigned *__restrict__ flag_count) {
+  extern __shared__ float sm[];
+  float *sA = sm;                       // nkb*T*64
+  float *sOff = sm + (size_t)nkb * T * 64;  // nkb*32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < nkb * T * 64; e += 256) sA[e] = apack[e];
+  for (int e = tid; e < nkb * 32; e += 256) sOff[e] = offp[e];
+  __syncthreads();
+  const float cmax2 = __uint_as_float(*cmax2_bits);
+  const int half = lane >> 5;
+
+  for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += (long long)gridDim.x * 4) {
+    const float *px = xq + (size_t)(2 * pp) * T * 64 + lane;
+    float bx[T], by[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      bx[t] = px[(size_t)t * 64];
+      by[t] = px[(size_t)(T + t) * 64];
+    }
+    // |x|^2 of the row this lane will own after the swap
+    float nx = 0.f, ny = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; t++) { nx += bx[t] * bx[t]; ny += by[t] * by[t]; }
+    {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(nx), __float_as_uint(ny), false, false);
+      nx = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // 2E band (see file header); non-finite inputs make it NaN => row flagged below
+    const float e2 = errk * (cmax2 + 2.0f * __fsqrt_rn(nx * cmax2)) + 1e-30f;
+
+    float pmin = FLT_MAX;
+    int best = -1;
+    unsigned long long amb = 0ull;
+
+    // one centroid block = 2*T MFMAs (tiles X and Y), C-init = offsets
+    auto mfma_block = [&](int kb, f32x16 &ax, f32x16 &ay) {
+      f32x16 cinit;
+      const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 4 * half);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float4 o = so[2 * g];   // centroids 8g + 4*half + (0..3)
+        cinit[4 * g + 0] = o.x; cinit[4 * g + 1] = o.y; cinit[4 * g + 2] = o.z; cinit[4 * g + 3] = o.w;
+      }
+      ax = cinit;
+      ay = cinit;
+      const float *pa = sA + (size_t)kb * T * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        float a = pa[t * 64];
+        ax = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bx[t], ax, 0, 0, 0);
+        ay = __builtin_amdgcn_mfma_f32_32x32x2f32(a, by[t], ay, 0, 0, 0);
+      }
+    };
+
+    f32x16 ax, ay;
+    mfma_block(0, ax, ay);
+    for (int kb = 0; kb < nkb; kb++) {
+      // software pipeline: the matrix pipe works on block kb+1 while the VALU scans block kb
+      f32x16 nax = ax, nay = ay;
+      if (kb + 1 < nkb) mfma_block(kb + 1, nax, nay);
+      // lanes 0-31 end up with tile X's row (lane), lanes 32-63 with tile Y's row (lane-32):
+      // ax[r] = centroids 8(r>>2) + (r&3), ay[r] = centroids 8(r>>2) + 4 + (r&3) of this block
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
+        ax[r] = __uint_as_float(sw[0]);
+        ay[r] = __uint_as_float(sw[1]);
+      }
+      // The reference's scan over c on d' (ascending centroid index), arranged so that the
+      // only serial dependency is ONE v_min per value (the running minimum); the band test
+      // and the winner search hang off it in parallel:
+      //   q[j]   = min(q[j-1], v[j])                      running minimum (q[-1] = pmin)
+      //   amb   |= |v[j] - q[j-1]| <= 2E                  comparison too close to call
+      //   bl     = first j with v[j] == q[31]             winner inside the block, if any
+      float vv[32], q[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) vv[j] = ((j >> 2) & 1) ? ay[4 * (j >> 3) + (j & 3)] : ax[4 * (j >> 3) + (j & 3)];
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const float prev = j == 0 ? pmin : q[j - 1];
+        // plain v_min_f32: the intrinsic form would add a canonicalising v_max per value
+        asm("v_min_f32 %0, %1, %2" : "=v"(q[j]) : "v"(prev), "v"(vv[j]));
+        amb |= __ballot(__builtin_fabsf(vv[j] - prev) <= e2);
+      }
+      const float pafter = q[31];
+      int bl = -1;
+#pragma unroll
+      for (int j = 31; j >= 0; j--) bl = vv[j] == pafter ? j : bl;
+      best = pafter < pmin ? kb * 32 + bl : best;
+      pmin = pafter;
+      ax = nax;
+      ay = nay;
+    }
+
+    const long long row = pp * 64 + lane;
+    const bool in_range = row < n;
+    const bool my_amb = ((amb >> lane) & 1ull) != 0ull;
+    const bool flagged = in_range && (my_amb || best < 0 || !(e2 < INFINITY) || !(fabsf(pmin) < INFINITY));
+    if (in_range && !flagged) assign[row] = best;
+    const unsigned long long fm = __ballot(flagged);
+    if (fm) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(flag_count, (unsigned)__popcll(fm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (flagged) flag_rows[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)row;
+    }
+  }
+}
+
+bool mfma_assign_supported(int s, int k) {
+  if (getenv("GULON_KMEANS_NO_MFMA")) return false;
+  int T = (s + 1) / 2;
+  int nkb = (k + 31) / 32;
+  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 32) * sizeof(float);
+  return s >= 1 && T <= 8 && lds <= 60 * 1024;
+}
+
+void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps, hipStream_t st) {
+  ps.n = n; ps.from = from; ps.s = s; ps.T = (s + 1) / 2;
+  long long ntile = ((long long)n + 31) / 32;
+  ntile = (ntile + 1) / 2 * 2;   // whole pairs
+  long long total = ntile * ps.T * 64;
+  ps.xq.ensure((size_t)std::max<long long>(total, 1));
+  if (total)
+    hipLaunchKernelGGL(pack_slice_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dX, n, ld, from, s, ps.T,
+                       total, ps.xq.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Runs the filter.  d_assign receives the answer of every unflagged row; flagged rows are
+// appended to ws.flag_rows and *ws.flag_count (device) holds their number.
+void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float *dC, int k, int *d_assign,
+                        hipStream_t st) {
+  const int s = ps.s, T = ps.T, n = ps.n;
+  const int nkb = (k + 31) / 32;
+  ws.apack.ensure((size_t)nkb * T * 64);
+  ws.offp.ensure((size_t)nkb * 32);
+  ws.cmax2.ensure(1);
+  ws.flag_rows.ensure((size_t)std::max(n, 1));
+  ws.flag_count.ensure(1);
+  HIP_CHECK(hipMemsetAsync(ws.cmax2.p, 0, sizeof(unsigned), st));
+  HIP_CHECK(hipMemsetAsync(ws.flag_count.p, 0, sizeof(unsigned), st));
+  int nthreads = std::max(nkb * T * 64, nkb * 32);
+  hipLaunchKernelGGL(pack_centroids_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, st, dC, ws.off.p, k, s, T,
+                     nkb, ws.apack.p, ws.offp.p, ws.cmax2.p);
+  const long long npairs = ((long long)n + 63) / 64;
+  // 2E = 2.1 * (2s+4) * 2^-24 * (|c|max^2 + 2|x||c|max): margins cover sqrt/norm rounding
+  const float errk = 2.1f * (float)(2 * s + 4) * 5.9604645e-8f;
+  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 32) * sizeof(float);
+  int grid = (int)std::min<long long>((npairs + 3) / 4, 256 * 8);
+  if (grid < 1) grid = 1;
+#define AM(TT)                                                                                                   \
+  hipLaunchKernelGGL(assign_mfma<TT>, dim3(grid), dim3(256), lds, st, ps.xq.p, n, npairs, ws.apack.p, ws.offp.p, \
+                     nkb, ws.cmax2.p, errk, d_assign, ws.flag_rows.p, ws.flag_count.p)
+  switch (T) {
+    case 1: AM(1); break;
+    case 2: AM(2); break;
+    case 3: AM(3); break;
+    case 4: AM(4); break;
+    case 5: AM(5); break;
+    case 6: AM(6); break;
+    case 7: AM(7); break;
+    case 8: AM(8); break;
+    default: GULON_UNSUPPORTED(true, "MFMA assign: sub-dimension %d too large", s);
+  }
+#undef AM
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace gulon
