@@ -260,15 +260,32 @@ __global__ __launch_bounds__(256) void sort_hist(const int *__restrict__ assign,
     for (int c = lane; c < k; c += 64) hist[(size_t)chunk * k + c] = h[c];
 }
 
-// thread per cluster: exclusive scan over chunks; then cluster starts
-__global__ void sort_scan(unsigned *__restrict__ hist, long long nchunks, int k, unsigned *__restrict__ count,
-                          unsigned *__restrict__ start) {
+// two-level exclusive scan of the per-chunk histograms (per cluster, over chunks):
+// level 1: one thread per (group of SCAN_GROUP chunks, cluster) scans its chunks in place
+constexpr int SCAN_GROUP = 64;
+__global__ void sort_scan_groups(unsigned *__restrict__ hist, long long nchunks, int k,
+                                 unsigned *__restrict__ gtot) {
+  int c = blockIdx.y * blockDim.x + threadIdx.x;
+  long long g = blockIdx.x;
+  if (c >= k) return;
+  long long c0 = g * SCAN_GROUP, c1 = c0 + SCAN_GROUP < nchunks ? c0 + SCAN_GROUP : nchunks;
+  unsigned run = 0;
+  for (long long ch = c0; ch < c1; ch++) {
+    unsigned v = hist[(size_t)ch * k + c];
+    hist[(size_t)ch * k + c] = run;
+    run += v;
+  }
+  gtot[(size_t)g * k + c] = run;
+}
+// level 2: one thread per cluster scans the group totals; then cluster starts
+__global__ void sort_scan_top(unsigned *__restrict__ gtot, long long ngroups, int k, unsigned *__restrict__ count,
+                              unsigned *__restrict__ start) {
   extern __shared__ unsigned cnt[];  // k
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
     unsigned run = 0;
-    for (long long ch = 0; ch < nchunks; ch++) {
-      unsigned v = hist[(size_t)ch * k + c];
-      hist[(size_t)ch * k + c] = run;
+    for (long long g = 0; g < ngroups; g++) {
+      unsigned v = gtot[(size_t)g * k + c];
+      gtot[(size_t)g * k + c] = run;
       run += v;
     }
     cnt[c] = run;
@@ -281,10 +298,13 @@ __global__ void sort_scan(unsigned *__restrict__ hist, long long nchunks, int k,
   }
 }
 
-// each wave places its chunk's rows in order: order[start[c] + rank] = row
+// each wave places its chunk's rows in order and copies their column slice to the
+// cluster-sorted buffer: sorted[(start[c] + rank) * s + j] = X[row][from + j]
 __global__ __launch_bounds__(256) void sort_place(const int *__restrict__ assign, int n, int k,
                                                   const unsigned *__restrict__ hist,
-                                                  const unsigned *__restrict__ start, int *__restrict__ order) {
+                                                  const unsigned *__restrict__ gtot,
+                                                  const unsigned *__restrict__ start, const float *__restrict__ X,
+                                                  int ld, int from, int s, float *__restrict__ sorted) {
   extern __shared__ unsigned sh[];  // 4 * k running positions
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned *run = sh + wave * k;
@@ -292,49 +312,56 @@ __global__ __launch_bounds__(256) void sort_place(const int *__restrict__ assign
   long long r0 = chunk * SORT_ROWS_PER_WAVE;
   if (r0 >= n) return;
   long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
-  for (int c = lane; c < k; c += 64) run[c] = start[c] + hist[(size_t)chunk * k + c];
+  const long long grp = chunk / SCAN_GROUP;
+  for (int c = lane; c < k; c += 64) run[c] = start[c] + gtot[(size_t)grp * k + c] + hist[(size_t)chunk * k + c];
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (long long base = r0; base < r1; base += 64) {
     long long r = base + lane;
     bool valid = r < r1;
     int key = valid ? assign[r] : -1;
+    unsigned pos = 0;
     unsigned long long todo = __ballot(valid);
     while (todo) {
       int l = __ffsll((long long)todo) - 1;
-      int k0 = __shfl(key, l);
+      int k0 = __builtin_amdgcn_readlane(key, l);
       unsigned long long mk = __ballot(valid && key == k0);
       unsigned b = run[k0];                      // wave-uniform read
-      if (valid && key == k0) order[b + __popcll(mk & lt)] = (int)r;
+      if (valid && key == k0) pos = b + __popcll(mk & lt);
       if (lane == l) run[k0] = b + __popcll(mk);
       todo &= ~mk;
+    }
+    if (valid) {
+      const float *src = X + (size_t)r * ld + from;
+      float *dst = sorted + (size_t)pos * s;
+      for (int j = 0; j < s; j++) dst[j] = src[j];
     }
   }
 }
 
 // one thread per (cluster, dim): c_j <- c_j + (x_j - c_j)/n over the cluster's rows
 // in row order (KMeans.scala:211-224).  IEEE division (__fdiv_rn), int->float RNE.
-__global__ __launch_bounds__(256) void update_chains(const float *__restrict__ X, int ld, int from, int s, int k,
-                                                     const int *__restrict__ order,
-                                                     const unsigned *__restrict__ count,
-                                                     const unsigned *__restrict__ start, float *__restrict__ C) {
+// The rows of a cluster are contiguous in `sorted`, so the loads do not depend on the
+// chain and are issued U steps ahead of the sequential divide-add recurrence.
+__global__ __launch_bounds__(64) void update_chains(const float *__restrict__ sorted, int s, int k,
+                                                    const unsigned *__restrict__ count,
+                                                    const unsigned *__restrict__ start, float *__restrict__ C) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k * s) return;
   int c = t / s, j = t - c * s;
   const unsigned len = count[c];
-  const int *ord = order + start[c];
-  const float *col = X + from + j;
+  const float *col = sorted + (size_t)start[c] * s + j;
   float p = 0.f;
   unsigned i = 0;
-  constexpr int U = 8;
+  constexpr int U = 16;
   for (; i + U <= len; i += U) {
     float xv[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) xv[u] = col[(size_t)ord[i + u] * ld];
+    for (int u = 0; u < U; u++) xv[u] = col[(size_t)(i + u) * s];
 #pragma unroll
     for (int u = 0; u < U; u++) p = p + __fdiv_rn(xv[u] - p, (float)(int)(i + u + 1));
   }
   for (; i < len; i++) {
-    float xv = col[(size_t)ord[i] * ld];
+    float xv = col[(size_t)i * s];
     p = p + __fdiv_rn(xv - p, (float)(int)(i + 1));
   }
   C[t] = p;
@@ -353,7 +380,10 @@ static int pick_smax(int s) {
   return s;
 }
 
+KmeansWorkspace::~KmeansWorkspace() { if (host) (void)hipHostFree(host); }
+
 void KmeansWorkspace::ensure(int n, int k, int s) {
+  if (!host) HIP_CHECK(hipHostMalloc((void **)&host, sizeof(HostWords)));
   int smax = pick_smax(s);
   cpad.ensure((size_t)k * smax);
   off.ensure(k);
@@ -363,43 +393,28 @@ void KmeansWorkspace::ensure(int n, int k, int s) {
   long long nchunks = ceil_div(std::max(n, 1), SORT_ROWS_PER_WAVE);
   long long nchunks_pad = ((nchunks + 3) / 4) * 4;
   hist.ensure((size_t)nchunks_pad * k);
+  gtot.ensure((size_t)ceil_div(nchunks_pad, SCAN_GROUP) * k);
   count.ensure(k);
   start.ensure(k);
-  order.ensure((size_t)std::max(n, 1));
+  sorted.ensure((size_t)std::max(n, 1) * std::max(s, 1));
   mismatch.ensure(1);
 }
 
-// KMeans.assign / parAssign on device arrays.  d_assign is written only where a
-// centroid won (caller initialises it).  rng_batch <= 0: one stream over all rows.
-void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
-                       int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps) {
-  if (n <= 0) return;
-  ws.ensure(n, k, s);
-  const int smax = pick_smax(s);
-  hipLaunchKernelGGL(prep_centroids, dim3(ceil_div(k, 64)), dim3(64), 0, st, dC, k, s, smax, ws.cpad.p, ws.off.p);
-  HIP_CHECK(hipMemsetAsync(ws.tie_total.p, 0, sizeof(unsigned long long), st));
-
-  // stage 1 (optional): MFMA filter decides every row whose scan is unambiguous
-  const int *rows = nullptr;
-  int nrows = n;
-  const bool filtered = ps != nullptr && mfma_assign_supported(s, k);
-  if (filtered) {
-    assign_mfma_filter(ws, *ps, dC, k, d_assign, st);
-    unsigned nf = 0;
-    HIP_CHECK(hipMemcpyAsync(&nf, ws.flag_count.p, sizeof(nf), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    ws.last_flagged = nf;
-    ws.last_draws = 0;
-    if (nf == 0) return;
-    rows = ws.flag_rows.p;
-    nrows = (int)nf;
-  }
-
-  // stage 2: exact VALU scan (all rows, or only the flagged ones)
-  const int grid = ceil_div(nrows, 256);
-#define AE(S)                                                                                                    \
-  hipLaunchKernelGGL(assign_exact<S>, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, ws.off.p, k, \
-                     rows, nrows, d_assign, ws.ties.p, ws.tie_total.p)
+// ---------------------------------------------------------------------------
+// KMeans.assign / parAssign on device arrays, as three enqueue stages separated by stream
+// synchronisations (the host needs two counters: #flagged rows, #RNG draws).  The stages
+// let the trainer run many independent problems on their own streams and pay the
+// synchronisations once per iteration instead of once per problem.
+// d_assign is written only where a centroid won (caller initialises it).
+// rng_batch <= 0: one java.util.Random stream over all rows.
+// ---------------------------------------------------------------------------
+static void launch_exact(AssignJob &j) {
+  KmeansWorkspace &ws = *j.ws;
+  const int smax = pick_smax(j.s);
+  const int grid = ceil_div(j.nrows, 256);
+#define AE(S)                                                                                                      \
+  hipLaunchKernelGGL(assign_exact<S>, dim3(grid), dim3(256), 0, j.st, j.dX, j.n, j.ld, j.from, j.s, ws.cpad.p,     \
+                     ws.off.p, j.k, j.rows, j.nrows, j.d_assign, ws.ties.p, ws.tie_total.p)
   switch (smax) {
     case 4: AE(4); break;
     case 8: AE(8); break;
@@ -408,34 +423,96 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
     case 64: AE(64); break;
     case 128: AE(128); break;
     default:
-      hipLaunchKernelGGL(assign_exact_generic, dim3(grid), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax,
-                         ws.off.p, k, rows, nrows, d_assign, ws.ties.p, ws.tie_total.p);
+      hipLaunchKernelGGL(assign_exact_generic, dim3(grid), dim3(256), 0, j.st, j.dX, j.n, j.ld, j.from, j.s, ws.cpad.p,
+                         smax, ws.off.p, j.k, j.rows, j.nrows, j.d_assign, ws.ties.p, ws.tie_total.p);
   }
 #undef AE
   HIP_CHECK(hipGetLastError());
-  unsigned long long total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, ws.tie_total.p, sizeof(total), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  ws.last_draws = total;
-  if (total == 0) return;
-  if (filtered) {
-    // draw counts exist only for the flagged rows: build the dense per-row array (0 elsewhere)
-    HIP_CHECK(hipMemsetAsync(ws.local.p, 0, sizeof(unsigned) * (size_t)n, st));
-    hipLaunchKernelGGL(scatter_ties, dim3(grid), dim3(256), 0, st, rows, nrows, ws.ties.p, ws.local.p);
-    HIP_CHECK(hipMemcpyAsync(ws.ties.p, ws.local.p, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(&ws.host->total, ws.tie_total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, j.st));
+}
+
+// stage 1: centroid prep, then either the MFMA filter (+ flagged-row count) or the exact
+// scan of every row (+ draw count)
+void assign_stage1(AssignJob &j) {
+  j.done = j.n <= 0;
+  if (j.done) return;
+  KmeansWorkspace &ws = *j.ws;
+  ws.ensure(j.n, j.k, j.s);
+  ws.last_draws = 0;
+  ws.last_flagged = 0;
+  const int smax = pick_smax(j.s);
+  hipLaunchKernelGGL(prep_centroids, dim3(ceil_div(j.k, 64)), dim3(64), 0, j.st, j.dC, j.k, j.s, smax, ws.cpad.p,
+                     ws.off.p);
+  HIP_CHECK(hipMemsetAsync(ws.tie_total.p, 0, sizeof(unsigned long long), j.st));
+  j.filtered = j.ps != nullptr && mfma_assign_supported(j.s, j.k);
+  if (j.filtered) {
+    assign_mfma_filter(ws, *j.ps, j.dC, j.k, j.d_assign, j.st);
+    HIP_CHECK(hipMemcpyAsync(&ws.host->flagged, ws.flag_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, j.st));
+  } else {
+    j.rows = nullptr;
+    j.nrows = j.n;
+    launch_exact(j);
   }
-  // place every drawing row in its RNG stream and replay it
-  const int seg_len = rng_batch > 0 ? rng_batch : n;
+}
+
+// stage 2 (after a stream sync): exact scan of the flagged rows, or -- unfiltered -- the
+// tie replay
+static void launch_tie_replay(AssignJob &j) {
+  KmeansWorkspace &ws = *j.ws;
+  const int n = j.n, smax = pick_smax(j.s);
+  const int seg_len = j.rng_batch > 0 ? j.rng_batch : n;
   const int nseg = ceil_div(n, seg_len);
   const int bps = ceil_div(seg_len < n ? seg_len : n, 1024);
   ws.block_tot.ensure((size_t)nseg * bps);
   ws.block_off.ensure((size_t)nseg * bps);
-  hipLaunchKernelGGL(tie_block_sums, dim3(bps, nseg), dim3(1024), 0, st, ws.ties.p, n, seg_len, bps, ws.local.p,
+  hipLaunchKernelGGL(tie_block_sums, dim3(bps, nseg), dim3(1024), 0, j.st, ws.ties.p, n, seg_len, bps, ws.local.p,
                      ws.block_tot.p);
-  hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, st, ws.block_tot.p, bps, ws.block_off.p);
-  hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ld, from, s, ws.cpad.p, smax, ws.off.p,
-                     k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, d_assign);
+  hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, j.st, ws.block_tot.p, bps, ws.block_off.p);
+  hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(n, 256)), dim3(256), 0, j.st, j.dX, n, j.ld, j.from, j.s,
+                     ws.cpad.p, smax, ws.off.p, j.k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, j.d_assign);
   HIP_CHECK(hipGetLastError());
+}
+
+void assign_stage2(AssignJob &j) {
+  if (j.done) return;
+  KmeansWorkspace &ws = *j.ws;
+  if (j.filtered) {
+    ws.last_flagged = ws.host->flagged;
+    if (ws.host->flagged == 0) { j.done = true; return; }
+    j.rows = ws.flag_rows.p;
+    j.nrows = (int)ws.host->flagged;
+    launch_exact(j);
+  } else {
+    ws.last_draws = ws.host->total;
+    if (ws.host->total) launch_tie_replay(j);
+    j.done = true;
+  }
+}
+
+// stage 3 (after a stream sync; filtered jobs only): tie replay over the flagged rows
+void assign_stage3(AssignJob &j) {
+  if (j.done) return;
+  KmeansWorkspace &ws = *j.ws;
+  ws.last_draws = ws.host->total;
+  if (ws.host->total) {
+    // draw counts exist only for the flagged rows: build the dense per-row array (0 elsewhere)
+    HIP_CHECK(hipMemsetAsync(ws.local.p, 0, sizeof(unsigned) * (size_t)j.n, j.st));
+    hipLaunchKernelGGL(scatter_ties, dim3(ceil_div(j.nrows, 256)), dim3(256), 0, j.st, j.rows, j.nrows, ws.ties.p,
+                       ws.local.p);
+    HIP_CHECK(hipMemcpyAsync(ws.ties.p, ws.local.p, sizeof(unsigned) * (size_t)j.n, hipMemcpyDeviceToDevice, j.st));
+    launch_tie_replay(j);
+  }
+  j.done = true;
+}
+
+void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
+                       int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps) {
+  AssignJob j;
+  j.ws = &ws; j.dX = dX; j.n = n; j.ld = ld; j.from = from; j.s = s; j.dC = dC; j.k = k; j.rng_batch = rng_batch;
+  j.d_assign = d_assign; j.st = st; j.ps = ps;
+  assign_stage1(j);
+  if (!j.done) { HIP_CHECK(hipStreamSynchronize(st)); assign_stage2(j); }
+  if (!j.done) { HIP_CHECK(hipStreamSynchronize(st)); assign_stage3(j); }
 }
 
 // KMeans.fromAssignment on device arrays -> dC (k x s)
@@ -448,14 +525,17 @@ void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
   }
   long long nchunks = ceil_div(n, SORT_ROWS_PER_WAVE);
   int blocks = ceil_div(nchunks, 4);
+  long long ngroups = ceil_div(nchunks, SCAN_GROUP);
   size_t shm = sizeof(unsigned) * 4 * (size_t)k;
   hipLaunchKernelGGL(sort_hist, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p);
-  hipLaunchKernelGGL(sort_scan, dim3(1), dim3(256), sizeof(unsigned) * (size_t)k, st, ws.hist.p, nchunks, k,
+  hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256)), dim3(256), 0, st, ws.hist.p, nchunks,
+                     k, ws.gtot.p);
+  hipLaunchKernelGGL(sort_scan_top, dim3(1), dim3(256), sizeof(unsigned) * (size_t)k, st, ws.gtot.p, ngroups, k,
                      ws.count.p, ws.start.p);
-  hipLaunchKernelGGL(sort_place, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p, ws.start.p,
-                     ws.order.p);
-  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * s, 64)), dim3(64), 0, st, dX, ld, from, s, k,
-                     ws.order.p, ws.count.p, ws.start.p, dC);
+  hipLaunchKernelGGL(sort_place, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p, ws.gtot.p, ws.start.p,
+                     dX, ld, from, s, ws.sorted.p);
+  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * s, 64)), dim3(64), 0, st, ws.sorted.p, s, k,
+                     ws.count.p, ws.start.p, dC);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -487,77 +567,108 @@ static void step_stats(const float *prev, const float *next, int k, int s, gulon
 }
 
 // KMeans.computeClusters (KMeans.scala:134-157) for `np` independent problems
-// (from[p], s[p], seed[p]) over the same n x ld data, run iteration-synchronously.
+// (from[p], s[p], seed[p]) over the same n x ld data, run iteration-synchronously: every
+// problem owns a stream and a workspace, so the small latency-bound kernels (sequential
+// update chains, sorts, tie replays) of different sub-quantizers overlap on the GPU.
 // c_out[p] receives k x s[p] floats.
 void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from, const int *sdim, const int *seeds,
                         int k, int max_iterations, float *const *c_out, gulon_kmeans_report *reports,
                         int max_reports, int32_t *n_reports) {
   GULON_REQUIRE(n >= 1, "KMeans.init needs at least one row (n = %d)", n);   // rng.nextInt(0) throws on the JVM
-  hipStream_t st = nullptr;
-  KmeansWorkspace ws;
   struct Prob {
+    KmeansWorkspace ws;
+    hipStream_t st = nullptr;
     DevBuf<float> c_prev, c_next;
-    DevBuf<int> a_prev, a_next;
+    DevBuf<int> a_prev, a_next, d_rows;
+    DevBuf<unsigned> mism;
     std::vector<float> h_prev, h_next;
     PackedSlice packed;      // MFMA-ready copy of this problem's column slice
+    AssignJob job;
     bool use_mfma = false;
     bool done = false;
     int nrep = 0;
+    ~Prob() { if (st) (void)hipStreamDestroy(st); }
   };
   std::vector<Prob> P(np);
   auto push_report = [&](int p, const gulon_kmeans_report &r) {
     if (reports && P[p].nrep < max_reports) reports[(size_t)p * max_reports + P[p].nrep] = r;
     P[p].nrep++;
   };
-  DevBuf<int> d_rows(k);
+  auto make_job = [&](int p, const float *dC, int *d_assign) {
+    Prob &pr = P[p];
+    AssignJob &j = pr.job;
+    j = AssignJob();
+    j.ws = &pr.ws; j.dX = dX; j.n = n; j.ld = ld; j.from = from[p]; j.s = sdim[p]; j.dC = dC; j.k = k;
+    j.rng_batch = 25000; j.d_assign = d_assign; j.st = pr.st; j.ps = pr.use_mfma ? &pr.packed : nullptr;
+  };
+  // run stages 2 and 3 of every listed problem, one synchronisation round per stage
+  auto finish_assigns = [&](const std::vector<int> &act) {
+    for (int stage = 2; stage <= 3; stage++) {
+      bool pending = false;
+      for (int p : act) pending |= !P[p].job.done;
+      if (!pending) break;
+      for (int p : act) if (!P[p].job.done) HIP_CHECK(hipStreamSynchronize(P[p].st));
+      for (int p : act) { if (stage == 2) assign_stage2(P[p].job); else assign_stage3(P[p].job); }
+    }
+  };
+
+  std::vector<int> all(np);
   for (int p = 0; p < np; p++) {
+    all[p] = p;
     const int s = sdim[p];
     Prob &pr = P[p];
+    HIP_CHECK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
     pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
     pr.a_prev.alloc(n); pr.a_next.alloc(n);
+    pr.mism.alloc(1);
     pr.h_prev.resize((size_t)k * s); pr.h_next.resize((size_t)k * s);
     // KMeans.init (KMeans.scala:188-196)
     std::vector<int> rows(k);
     JRandom rng((int64_t)seeds[p]);
     for (int c = 0; c < k; c++) rows[c] = rng.next_int(n);
-    d_rows.upload(rows.data(), k, st);
-    hipLaunchKernelGGL(gather_centroids, dim3(ceil_div((long long)k * s, 256)), dim3(256), 0, st, dX, ld, from[p], s,
-                       d_rows.p, k, pr.c_prev.p);
+    pr.d_rows.alloc(k);
+    HIP_CHECK(hipMemcpy(pr.d_rows.p, rows.data(), sizeof(int) * k, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gather_centroids, dim3(ceil_div((long long)k * s, 256)), dim3(256), 0, pr.st, dX, ld, from[p], s,
+                       pr.d_rows.p, k, pr.c_prev.p);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, st));
+    HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, pr.st));
     pr.use_mfma = mfma_assign_supported(s, k);
-    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, st);
-    kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_prev.p, k, 25000, pr.a_prev.p, st,
-                      pr.use_mfma ? &pr.packed : nullptr);
-    pr.c_prev.download(pr.h_prev.data(), (size_t)k * s, st);
+    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, pr.st);
+    make_job(p, pr.c_prev.p, pr.a_prev.p);
+    assign_stage1(pr.job);
     push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
   }
-  HIP_CHECK(hipStreamSynchronize(st));
-  DevBuf<unsigned> mism(np);
-  std::vector<unsigned> h_mism(np);
+  finish_assigns(all);
+  for (int p = 0; p < np; p++) {
+    P[p].c_prev.download(P[p].h_prev.data(), (size_t)k * sdim[p], P[p].st);
+    HIP_CHECK(hipStreamSynchronize(P[p].st));
+  }
+
   for (int i = 0; i <= max_iterations;) {
-    bool any = false;
-    HIP_CHECK(hipMemsetAsync(mism.p, 0, sizeof(unsigned) * np, st));
-    for (int p = 0; p < np; p++) {
+    std::vector<int> act;
+    for (int p = 0; p < np; p++) if (!P[p].done) act.push_back(p);
+    if (act.empty()) break;
+    for (int p : act) {
       Prob &pr = P[p];
-      if (pr.done) continue;
-      any = true;
-      const int s = sdim[p];
-      kmeans_update_dev(ws, dX, n, ld, from[p], s, k, pr.a_prev.p, pr.c_next.p, st);
-      HIP_CHECK(hipMemsetAsync(pr.a_next.p, 0, sizeof(int) * (size_t)n, st));   // fresh Array[Int] per parAssign
-      kmeans_assign_dev(ws, dX, n, ld, from[p], s, pr.c_next.p, k, 25000, pr.a_next.p, st,
-                        pr.use_mfma ? &pr.packed : nullptr);
-      hipLaunchKernelGGL(count_mismatch, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr.a_prev.p, pr.a_next.p, n,
-                         mism.p + p);
-      pr.c_next.download(pr.h_next.data(), (size_t)k * s, st);
+      kmeans_update_dev(pr.ws, dX, n, ld, from[p], sdim[p], k, pr.a_prev.p, pr.c_next.p, pr.st);
+      HIP_CHECK(hipMemsetAsync(pr.a_next.p, 0, sizeof(int) * (size_t)n, pr.st));   // fresh Array[Int] per parAssign
+      make_job(p, pr.c_next.p, pr.a_next.p);
+      assign_stage1(pr.job);
     }
-    if (!any) break;
-    mism.download(h_mism.data(), np, st);
-    HIP_CHECK(hipStreamSynchronize(st));
-    bool all_conv = true;
-    for (int p = 0; p < np; p++) {
+    finish_assigns(act);
+    std::vector<unsigned> h_mism(np, 0);
+    for (int p : act) {
       Prob &pr = P[p];
-      if (pr.done) continue;
+      HIP_CHECK(hipMemsetAsync(pr.mism.p, 0, sizeof(unsigned), pr.st));
+      hipLaunchKernelGGL(count_mismatch, dim3(ceil_div(n, 256)), dim3(256), 0, pr.st, pr.a_prev.p, pr.a_next.p, n,
+                         pr.mism.p);
+      pr.c_next.download(pr.h_next.data(), (size_t)k * sdim[p], pr.st);
+      pr.mism.download(&h_mism[p], 1, pr.st);
+    }
+    for (int p : act) HIP_CHECK(hipStreamSynchronize(P[p].st));
+    bool all_conv = true;
+    for (int p : act) {
+      Prob &pr = P[p];
       bool converged = h_mism[p] == 0;                       // Arrays.equals(prev, next)
       gulon_kmeans_report r{i, converged ? 1 : 0, 0, 0.f, 0.f};
       step_stats(pr.h_prev.data(), pr.h_next.data(), k, sdim[p], &r);

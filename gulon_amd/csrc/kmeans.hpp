@@ -14,11 +14,17 @@ struct PackedSlice {
 };
 
 struct KmeansWorkspace {
+  struct HostWords { unsigned flagged; unsigned pad; unsigned long long total; };
+  HostWords *host = nullptr;           // pinned: counters copied back asynchronously
+  KmeansWorkspace() = default;
+  KmeansWorkspace(const KmeansWorkspace &) = delete;
+  KmeansWorkspace &operator=(const KmeansWorkspace &) = delete;
+  ~KmeansWorkspace();
   DevBuf<float> cpad, off;
   DevBuf<unsigned> ties, local, block_tot;
   DevBuf<unsigned long long> tie_total, block_off;
-  DevBuf<unsigned> hist, count, start, mismatch;
-  DevBuf<int> order;
+  DevBuf<unsigned> hist, gtot, count, start, mismatch;
+  DevBuf<float> sorted;                // column slice of the rows, grouped by cluster (stable)
   // MFMA filter
   DevBuf<float> apack, offp;
   DevBuf<unsigned> cmax2, flag_count, flag_ties;
@@ -32,6 +38,24 @@ bool mfma_assign_supported(int s, int k);
 void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps, hipStream_t st);
 void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float *dC, int k, int *d_assign,
                         hipStream_t st);
+
+// One assign call, split into enqueue stages (kmeans.hip): stage1 -> sync -> stage2 -> sync -> stage3.
+struct AssignJob {
+  KmeansWorkspace *ws = nullptr;
+  const float *dX = nullptr;
+  int n = 0, ld = 0, from = 0, s = 0;
+  const float *dC = nullptr;
+  int k = 0, rng_batch = 0;
+  int *d_assign = nullptr;
+  hipStream_t st = nullptr;
+  const PackedSlice *ps = nullptr;
+  bool filtered = false, done = false;
+  const int *rows = nullptr;
+  int nrows = 0;
+};
+void assign_stage1(AssignJob &j);
+void assign_stage2(AssignJob &j);
+void assign_stage3(AssignJob &j);
 
 // KMeans.assign / parAssign.  `ps` (nullable): packed copy of the slice => MFMA filter +
 // exact re-check of the flagged rows; without it every row takes the exact VALU kernel.
