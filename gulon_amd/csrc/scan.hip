@@ -64,27 +64,29 @@ __global__ void narrow_codes(const uint16_t *__restrict__ in, long long total, u
 // sequential, unfused.  INTERLEAVED: written as [q/4][j_pad][256][q%4] for the scan;
 // otherwise as the reference's [B][m][k].
 // ---------------------------------------------------------------------------
-template <bool INTERLEAVED>
+template <bool INTERLEAVED, int W>
 __global__ void build_tables(const float *__restrict__ cents, const int *__restrict__ from,
                              const int *__restrict__ sdim, int d, int m, int k, int m_pad,
                              const float *__restrict__ Q, int B, float *__restrict__ T) {
-  // one thread per (query group of 4, quantizer, centroid)
+  // one thread per (query group of W, quantizer, centroid)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int nqg = (B + 3) / 4;
+  int nqg = (B + W - 1) / W;
   long long total = (long long)nqg * m_pad * 256;
   if (t >= total) return;
   int c = (int)(t & 255);
   int j = (int)((t >> 8) % m_pad);
   int qg = (int)((t >> 8) / m_pad);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[W];
+#pragma unroll
+  for (int u = 0; u < W; u++) acc[u] = 0.f;
   if (j < m && c < k) {
     int fr = from[j], s = sdim[j];
     const float *cc = cents + (size_t)k * fr + (size_t)c * s;
     for (int tt = 0; tt < s; tt++) {
       float cv = cc[tt];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        int q = qg * 4 + u;
+      for (int u = 0; u < W; u++) {
+        int q = qg * W + u;
         if (q < B) {
           float dd = Q[(size_t)q * d + fr + tt] - cv;
           acc[u] += dd * dd;
@@ -93,11 +95,12 @@ __global__ void build_tables(const float *__restrict__ cents, const int *__restr
     }
   }
   if (INTERLEAVED) {
-    reinterpret_cast<float4 *>(T)[t] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int u = 0; u < W; u++) T[(size_t)t * W + u] = acc[u];
   } else if (j < m && c < k) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int q = qg * 4 + u;
+    for (int u = 0; u < W; u++) {
+      int q = qg * W + u;
       if (q < B) T[((size_t)q * m + j) * k + c] = acc[u];
     }
   }
@@ -122,36 +125,45 @@ __device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
   return (x >> (8 * (b & 3))) & 0xFFu;
 }
 
-template <int NSUB, int VEC, int THREADS, bool PRUNE>
+// W queries are interleaved per table entry: W = 4 -> ds_read_b128, 2 -> b64, 1 -> b32.
+template <int W> struct TabVec;
+template <> struct TabVec<4> { using type = float4; };
+template <> struct TabVec<2> { using type = float2; };
+template <> struct TabVec<1> { using type = float; };
+
+template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
 __global__ __launch_bounds__(THREADS) void scan_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
     int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
     int prune_from) {
-  constexpr int QT = 4 * NSUB;
+  constexpr int QT = W * NSUB;
   constexpr int NW = THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
-  extern __shared__ float4 lds[];
+  using TV = typename TabVec<W>::type;
+  extern __shared__ float4 lds_raw[];
+  const TV *lds = reinterpret_cast<const TV *>(lds_raw);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int tile = blockIdx.x;   // query tile (fastest: tiles of one chunk run together)
   const int chunk = blockIdx.y;
-  const int tab_entries = m_pad * 256;  // float4 per sub-table
+  const int tab_entries = m_pad * 256;  // entries (of W floats) per sub-table
 
   // Shared pruning thresholds, as the bits of non-negative floats (so unsigned min == float
   // min): tau_sh[q] >= the (K+1)-th smallest distance of query q over everything scanned so
   // far by ANY wave of ANY workgroup (gtau is the cross-workgroup copy).  A row whose
   // distance exceeds it can never be in the final top-(K+1), so it is dropped before the
   // (expensive, wave-serial) insertion.  Only speed depends on how fresh these values are.
-  unsigned *tau_sh = reinterpret_cast<unsigned *>(lds + tau_off4);
+  unsigned *tau_sh = reinterpret_cast<unsigned *>(lds_raw + tau_off4);
   if (tid < QT) tau_sh[tid] = __hip_atomic_load(&gtau[tile * QT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // stage the NSUB sub-tables of this query tile
   {
-    const float4 *src = tables + (size_t)tile * NSUB * tab_entries;
-    for (int e = tid; e < NSUB * tab_entries; e += THREADS) lds[e] = src[e];
+    const int n16 = NSUB * tab_entries * W / 4;   // float4 units
+    const float4 *src = tables + (size_t)tile * n16;
+    for (int e = tid; e < n16; e += THREADS) lds_raw[e] = src[e];
   }
   __syncthreads();
 
@@ -195,15 +207,18 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
     for (int g = 0; g < ng; g++) {
       Word wn = w;
       if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
-      const float4 *tj = lds + g * VEC * 256;
+      const TV *tj = lds + g * VEC * 256;
 #pragma unroll
       for (int seg = 0; seg < VEC / 4; seg++) {
         if (PRUNE && g * VEC + seg * 4 >= prune_from) {
 #pragma unroll
           for (int s = 0; s < NSUB; s++)
-            if (live[s])
-              live[s] = __ballot(acc[4 * s + 0] <= tsh[4 * s + 0] || acc[4 * s + 1] <= tsh[4 * s + 1] ||
-                                 acc[4 * s + 2] <= tsh[4 * s + 2] || acc[4 * s + 3] <= tsh[4 * s + 3]) != 0ull;
+            if (live[s]) {
+              bool in = false;
+#pragma unroll
+              for (int u = 0; u < W; u++) in = in || acc[W * s + u] <= tsh[W * s + u];
+              live[s] = __ballot(in) != 0ull;
+            }
         }
 #pragma unroll
         for (int s = 0; s < NSUB; s++) {
@@ -212,11 +227,10 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
             for (int bb = 0; bb < 4; bb++) {
               const int b = seg * 4 + bb;
               uint32_t c = code_byte<VEC>(w, b);
-              float4 t = tj[b * 256 + c + s * tab_entries];
-              acc[4 * s + 0] += t.x;
-              acc[4 * s + 1] += t.y;
-              acc[4 * s + 2] += t.z;
-              acc[4 * s + 3] += t.w;
+              TV t = tj[b * 256 + c + s * tab_entries];
+              const float *tf = reinterpret_cast<const float *>(&t);
+#pragma unroll
+              for (int u = 0; u < W; u++) acc[W * s + u] += tf[u];
             }
           }
         }
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
     unsigned long long any = 0;
 #pragma unroll
     for (int q = 0; q < QT; q++) {
-      unsigned long long mk = (!PRUNE || live[q / 4]) ? __ballot(valid && acc[q] <= tsh[q]) : 0ull;
+      unsigned long long mk = (!PRUNE || live[q / W]) ? __ballot(valid && acc[q] <= tsh[q]) : 0ull;
       masks[q] = mk;
       any |= mk;
     }
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
 
   // merge the NW per-wave lists of every query through LDS (tables are dead now)
   __syncthreads();
-  float *sv = reinterpret_cast<float *>(lds);
+  float *sv = reinterpret_cast<float *>(lds_raw);
   int *si = reinterpret_cast<int *>(sv + QT * NW * 64);
 #pragma unroll
   for (int q = 0; q < QT; q++) {
@@ -390,7 +404,7 @@ using namespace gulon;
 // ---------------------------------------------------------------------------
 struct gulon_index {
   int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
-  int vec = 16, ng = 1, m_pad = 16, nsub = 1;
+  int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
   DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
   DevBuf<float> cents;     // k*d
   DevBuf<int> from, sdim;  // m
@@ -417,12 +431,11 @@ constexpr size_t LDS_BUDGET = 144 * 1024;
 
 // launch shape knobs (environment overrides are for tuning experiments only)
 struct ScanTuning {
-  int threads = 1024;       // workgroup size: 512 or 1024 (16 waves hide the pruning checkpoints' LDS drain)
+  int threads = 1024;       // workgroup size (16 waves hide the pruning checkpoints' LDS drain)
   int target_blocks = 4096; // workgroups per launch aimed for
   int prune = 1;            // exact early termination on/off
   int prune_from = -1;      // first quantizer index with a pruning checkpoint (-1: m_pad/2)
   ScanTuning() {
-    if (const char *e = getenv("GULON_SCAN_THREADS")) { int v = atoi(e); if (v == 512 || v == 1024) threads = v; }
     if (const char *e = getenv("GULON_SCAN_BLOCKS")) { int v = atoi(e); if (v >= 1) target_blocks = v; }
     if (const char *e = getenv("GULON_SCAN_PRUNE")) prune = atoi(e) != 0;
     if (const char *e = getenv("GULON_SCAN_PRUNE_FROM")) prune_from = atoi(e);
@@ -430,17 +443,17 @@ struct ScanTuning {
 };
 static const ScanTuning &tuning() { static ScanTuning t; return t; }
 
-template <int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
+template <int W, int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
 void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
                    int until, int keff, hipStream_t st) {
-  size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * sizeof(float4);
-  size_t merge_bytes = (size_t)4 * NSUB * (SCAN_THREADS / 64) * 64 * 8;
+  size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * W * sizeof(float);
+  size_t merge_bytes = (size_t)W * NSUB * (SCAN_THREADS / 64) * 64 * 8;
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
   const int tau_off4 = (int)(lds_bytes / sizeof(float4));   // shared thresholds live after tables/merge area
   lds_bytes += 64;
   int prune_from = tuning().prune_from >= 0 ? tuning().prune_from : ix->m_pad / 2;
   if (prune_from < 4) prune_from = 4;
-  auto kern = scan_kernel<NSUB, VEC, SCAN_THREADS, PRUNE>;
+  auto kern = scan_kernel<W, NSUB, VEC, SCAN_THREADS, PRUNE>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
@@ -449,30 +462,29 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
   HIP_CHECK(hipGetLastError());
 }
 
-template <int NSUB, int VEC, int SCAN_THREADS>
+template <int W, int NSUB, int VEC>
 void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
                    int until, int keff, hipStream_t st) {
+  constexpr int TH = 1024;
   if (tuning().prune)
-    launch_scan_p<NSUB, VEC, SCAN_THREADS, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until,
-                                                 keff, st);
+    launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
   else
-    launch_scan_p<NSUB, VEC, SCAN_THREADS, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until,
-                                                  keff, st);
+    launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
 }
 
 void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
                  int until, int keff, hipStream_t st) {
-#define GO(NS, V)                                                                                              \
-  do {                                                                                                         \
-    if (tuning().threads == 1024)                                                                              \
-      launch_scan_t<NS, V, 1024>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);  \
-    else                                                                                                       \
-      launch_scan_t<NS, V, 512>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);   \
-  } while (0)
-  if (ix->vec == 16) {
-    if (ix->nsub == 4) GO(4, 16); else if (ix->nsub == 2) GO(2, 16); else GO(1, 16);
+#define GO(WW, NS, V) launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st)
+  if (ix->w == 4) {
+    if (ix->vec == 16) {
+      if (ix->nsub == 4) GO(4, 4, 16); else if (ix->nsub == 2) GO(4, 2, 16); else GO(4, 1, 16);
+    } else {
+      if (ix->nsub == 4) GO(4, 4, 4); else if (ix->nsub == 2) GO(4, 2, 4); else GO(4, 1, 4);
+    }
+  } else if (ix->w == 2) {
+    if (ix->vec == 16) GO(2, 1, 16); else GO(2, 1, 4);
   } else {
-    if (ix->nsub == 4) GO(4, 4); else if (ix->nsub == 2) GO(2, 4); else GO(1, 4);
+    if (ix->vec == 16) GO(1, 1, 16); else GO(1, 1, 4);
   }
 #undef GO
 }
@@ -487,7 +499,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
                     GULON_MAX_K);
   if (B == 0) return;
   const int keff = K + 1;
-  const int QT = 4 * ix->nsub;
+  const int W = ix->w;
+  const int QT = W * ix->nsub;
   const int ntiles = ceil_div(B, QT);
   const int rb_begin = from / 64;
   const int rb_end = ceil_div(until, 64);
@@ -523,16 +536,19 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   nchunks = ceil_div(rb_total, rb_per_chunk);
 
   const int Bp = ntiles * QT;
-  ix->tables.ensure((size_t)(Bp / 4) * ix->m_pad * 256 * 4);
+  ix->tables.ensure((size_t)Bp * ix->m_pad * 256);
   ix->part_v.ensure((size_t)Bp * nchunks * keff);
   ix->part_i.ensure((size_t)Bp * nchunks * keff);
   ix->gtau.ensure((size_t)Bp);
   HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
 
   {
-    long long total = (long long)(Bp / 4) * ix->m_pad * 256;
-    hipLaunchKernelGGL(build_tables<true>, dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p, ix->from.p,
-                       ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, ix->tables.p);
+    long long total = (long long)(Bp / W) * ix->m_pad * 256;
+#define BT(WW)                                                                                                  \
+  hipLaunchKernelGGL((build_tables<true, WW>), dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p,        \
+                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, ix->tables.p)
+    if (W == 4) BT(4); else if (W == 2) BT(2); else BT(1);
+#undef BT
     HIP_CHECK(hipGetLastError());
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -567,10 +583,13 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
     ix->vec = (m % 16 == 0) ? 16 : 4;
     ix->ng = ceil_div(m, ix->vec);
     ix->m_pad = ix->ng * ix->vec;
-    size_t per_sub = (size_t)ix->m_pad * 256 * 16;
-    GULON_UNSUPPORTED(per_sub > LDS_BUDGET, "m = %d quantizers need %zu B of LDS per 4-query table (> %zu)", m,
+    // queries interleaved per table entry: as many as LDS holds (m = 64 -> 2, m > 72 -> 1)
+    ix->w = 4;
+    while (ix->w > 1 && (size_t)ix->m_pad * 256 * ix->w * 4 > LDS_BUDGET) ix->w /= 2;
+    size_t per_sub = (size_t)ix->m_pad * 256 * ix->w * 4;
+    GULON_UNSUPPORTED(per_sub > LDS_BUDGET, "m = %d quantizers need %zu B of LDS for one query's table (> %zu)", m,
                       per_sub, LDS_BUDGET);
-    ix->nsub = (4 * per_sub <= LDS_BUDGET) ? 4 : (2 * per_sub <= LDS_BUDGET) ? 2 : 1;
+    ix->nsub = ix->w < 4 ? 1 : (4 * per_sub <= LDS_BUDGET) ? 4 : (2 * per_sub <= LDS_BUDGET) ? 2 : 1;
 
     std::vector<int> from, until, sdim(m);
     subvectors(d, m, from, until);
@@ -744,7 +763,7 @@ GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, 
     dfrom.upload(from.data(), m); dsd.upload(sdim.data(), m);
     dc.upload(cents, (size_t)k * d); dq.upload(queries, (size_t)b * d);
     long long total = (long long)((b + 3) / 4) * m * 256;
-    hipLaunchKernelGGL(build_tables<false>, dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
+    hipLaunchKernelGGL((build_tables<false, 4>), dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
                        m, dq.p, b, dt.p);
     HIP_CHECK(hipGetLastError());
     dt.download(t_out, (size_t)b * m * k);

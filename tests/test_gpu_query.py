@@ -61,6 +61,9 @@ def test_prepare_query_bit_exact(oracle, g, d, m, k, B):
     (1000, 128, 16, 256, 3, 10, 100, 105),          # fewer rows than K
     (1000, 128, 16, 256, 3, 10, 64, 64),            # empty range
     (70, 16, 16, 256, 1, 10, 0, None),
+    (20000, 128, 64, 256, 7, 10, 0, None),          # m = 64: 2-query interleave (ds_read_b64)
+    (6000, 200, 100, 256, 3, 10, 0, None),          # m = 100: 1-query tables (ds_read_b32)
+    (6000, 96, 48, 37, 5, 10, 77, 5000),
 ])
 def test_batch_query_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
     cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + d)
