@@ -395,6 +395,22 @@ void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists,
   HIP_CHECK(hipGetLastError());
 }
 
+void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st) {
+  long long total = (long long)(Bpad / W) * ix->m_pad * 256;
+  if (total <= 0) return;
+#define BT(WW)                                                                                             \
+  hipLaunchKernelGGL((build_tables<true, WW>), dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p,   \
+                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, tables)
+  if (W == 4) BT(4); else if (W == 2) BT(2); else BT(1);
+#undef BT
+  HIP_CHECK(hipGetLastError());
+}
+
+bool replay_enabled() {
+  static const bool on = [] { const char *e = getenv("GULON_TIE_REPLAY"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 }  // namespace gulon
 
 using namespace gulon;
@@ -402,29 +418,6 @@ using namespace gulon;
 // ---------------------------------------------------------------------------
 // index handle
 // ---------------------------------------------------------------------------
-struct gulon_index {
-  int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
-  int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
-  DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
-  DevBuf<float> cents;     // k*d
-  DevBuf<int> from, sdim;  // m
-  // scratch, grown on demand under `mu`
-  DevBuf<float> tables;
-  DevBuf<float> part_v;
-  DevBuf<int> part_i;
-  DevBuf<unsigned> gtau;   // per-query cross-workgroup pruning thresholds (float bits)
-  DevBuf<float> stage_q;
-  DevBuf<int> stage_oi, stage_oc, stage_of;
-  DevBuf<float> stage_od;
-  // optional hipEvent bracketing of the scan kernel (bench.py roofline line)
-  bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  std::mutex mu;
-  ~gulon_index() {
-    for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  }
-};
-
 namespace {
 
 constexpr size_t LDS_BUDGET = 144 * 1024;
@@ -542,15 +535,7 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   ix->gtau.ensure((size_t)Bp);
   HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
 
-  {
-    long long total = (long long)(Bp / W) * ix->m_pad * 256;
-#define BT(WW)                                                                                                  \
-  hipLaunchKernelGGL((build_tables<true, WW>), dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p,        \
-                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, ix->tables.p)
-    if (W == 4) BT(4); else if (W == 2) BT(2); else BT(1);
-#undef BT
-    HIP_CHECK(hipGetLastError());
-  }
+  launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->profile) {
     HIP_CHECK(hipEventCreate(&e0));
@@ -562,8 +547,15 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     HIP_CHECK(hipEventRecord(e1, st));
     ix->events.emplace_back(e0, e1);
   }
+  int *flags = d_of;
+  if (final_out && replay_enabled() && flags == nullptr) {   // the replay needs the tie flags even if the caller does not
+    ix->flags_scratch.ensure((size_t)B);
+    flags = ix->flags_scratch.p;
+  }
   launch_merge(final_out, ix->part_v.p, ix->part_i.p, nchunks, (long long)keff, (long long)nchunks * keff, B, K, d_oi,
-               d_od, d_oc, d_of, d_pv, d_pi, st);
+               d_od, d_oc, flags, d_pv, d_pi, st);
+  // queries with exact distance ties: replay the reference heap's insertion history
+  if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
 }
 
 }  // namespace

@@ -12,4 +12,44 @@ namespace gulon {
 void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists, long long stride_l,
                   long long stride_q, int B, int K, int *out_idx, float *out_dist, int *out_count,
                   int *out_flags, float *out_pv, int *out_pi, hipStream_t st);
+bool replay_enabled();
+}  // namespace gulon
+
+// PQIndex on the device (opaque to C callers)
+using gulon::DevBuf;
+struct gulon_index {
+  int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
+  int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
+  DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
+  DevBuf<float> cents;     // k*d
+  DevBuf<int> from, sdim;  // m
+  // scratch, grown on demand under `mu`
+  DevBuf<float> tables;
+  DevBuf<float> part_v;
+  DevBuf<int> part_i;
+  DevBuf<unsigned> gtau;   // per-query cross-workgroup pruning thresholds (float bits)
+  DevBuf<float> stage_q;
+  DevBuf<int> stage_oi, stage_oc, stage_of;
+  DevBuf<float> stage_od;
+  DevBuf<int> flags_scratch;
+  // exact tie replay (replay.hip)
+  DevBuf<int> rp_list, rp_count, rp_segcnt, rp_evcnt, rp_overflow, rp_evi, rp_precnt;
+  DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv;
+  // optional hipEvent bracketing of the scan kernel (bench.py roofline line)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::mutex mu;
+  ~gulon_index() {
+    for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+};
+
+
+namespace gulon {
+// Index.prepareQuery tables, W queries interleaved (scan.hip)
+void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st);
+// For every query flagged with an exact distance tie, recompute the result with the
+// reference's TopKHeap semantics (insertion history in row order) -- replay.hip
+void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
+                    int *d_oc, int *d_of, hipStream_t st);
 }  // namespace gulon

@@ -21,6 +21,7 @@ ERR_OOM = -5
 
 FLAG_BOUNDARY_TIE = 1
 FLAG_INTERIOR_TIE = 2
+FLAG_EXACT_REPLAY = 4
 MAX_K = 63
 
 

@@ -46,6 +46,8 @@ extern "C" {
 /* flags written per query by the top-k kernels (see DESIGN.md "tie rule") */
 #define GULON_FLAG_BOUNDARY_TIE 1 /* K-th and (K+1)-th smallest distances are equal */
 #define GULON_FLAG_INTERIOR_TIE 2 /* two equal distances inside the top K */
+#define GULON_FLAG_EXACT_REPLAY 4 /* tie resolved by replaying the reference heap's insertion history:
+                                     ids and order are exactly TopKHeap's (single, unsharded index only) */
 
 #define GULON_MAX_K 63 /* neighbours per query supported by the wavefront top-k */
 

@@ -31,7 +31,8 @@ def _check(oracle, res, oi, od, oc):
     for q, r in enumerate(res):
         assert len(r) == oc[q]
         assert np.array_equal(bits(r.distances), bits(od[q, :oc[q]]))
-        if r.flags == 0:
+        if r.flags == 0 or (r.flags & 4):
+            # no tie, or tie resolved by the exact TopKHeap replay: ids and order are the reference's
             assert r.rows.tolist() == oi[q, :oc[q]].tolist()
         else:   # equal distances: order inside a tie group is unspecified (IndexSpec.scala:24-32)
             assert sorted(r.rows.tolist()) == sorted(oi[q, :oc[q]].tolist()) or (r.flags & 1)
@@ -95,12 +96,41 @@ def test_ties_are_flagged_and_distances_match(oracle, g):
     res = ix.batch_query(9, Q)
     oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, 9)
     for q, r in enumerate(res):
-        assert r.flags != 0                                   # every row has an exact duplicate
-        assert np.array_equal(bits(r.distances), bits(od[q]))  # the multiset of distances is exact
-        assert r.rows.tolist() == sorted(r.rows.tolist(), key=lambda x: (float(r.distances[r.rows.tolist().index(x)]), x))
-        # deterministic rule: smallest (distance, row id)
-        for a, b in zip(r.rows[:-1], r.rows[1:]):
-            pass
+        assert r.flags & 3                                    # every row has an exact duplicate
+        assert r.flags & 4                                    # ... and the heap history was replayed
+        assert np.array_equal(bits(r.distances), bits(od[q]))
+        assert r.rows.tolist() == oi[q].tolist()              # exactly TopKHeap's ids, in its order
+    ix.close()
+
+
+@pytest.mark.parametrize("n,d,m,k,K,dup,frm,until", [(6000, 16, 4, 16, 9, 3000, 0, None), (40000, 32, 8, 4, 10, 0, 0, None),
+                                                    (30000, 16, 16, 2, 63, 0, 5, 29990), (2000, 8, 2, 3, 5, 0, 0, None),
+                                                    (100000, 128, 16, 256, 10, 50000, 0, None)])
+def test_exact_heap_replay_under_heavy_ties(oracle, g, n, d, m, k, K, dup, frm, until):
+    """Few distinct codes => massive exact ties; ids must equal the reference heap's, bit for bit."""
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + K, dup=dup)
+    Q = np.random.default_rng(K).standard_normal((5, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q, frm, until)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    for q, r in enumerate(res):
+        assert len(r) == oc[q]
+        assert np.array_equal(bits(r.distances), bits(od[q, :oc[q]]))
+        assert r.flags == 0 or (r.flags & 4), r.flags
+        assert r.rows.tolist() == oi[q, :oc[q]].tolist()
+    ix.close()
+
+
+def test_exact_heap_replay_whole_batch_flagged(oracle, g):
+    """More flagged queries than one replay wave of 64: every query of the batch is replayed."""
+    n, d, m, k, K, B = 20000, 16, 4, 4, 10, 150
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=99)
+    Q = np.random.default_rng(3).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    oi_g, od_g, oc_g, of_g = ix.batch_query_raw(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    assert np.all((of_g & 4) != 0)
+    assert np.array_equal(oi_g, oi) and np.array_equal(bits(od_g), bits(od))
     ix.close()
 
 
