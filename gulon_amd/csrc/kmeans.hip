@@ -13,6 +13,8 @@
 //            (ProductQuantizer.apply = m problems, seed = quantizer index).
 #include "kmeans.hpp"
 
+#include <chrono>
+
 namespace gulon {
 
 // ---------------------------------------------------------------------------
@@ -235,6 +237,15 @@ __global__ void scatter_ties(const int *__restrict__ rows, int nrows, const unsi
   if (t < nrows) dense[rows[t]] = ties[rows[t]];
 }
 
+__global__ void copy_slice(const float *__restrict__ X, int ld, int from, int s, long long total,
+                           float *__restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  long long r = t / s;
+  int j = (int)(t - r * s);
+  out[t] = X[(size_t)r * ld + from + j];
+}
+
 __global__ void narrow_assign_u8(const int *__restrict__ a, long long n, uint8_t *__restrict__ out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)a[i];
@@ -245,9 +256,14 @@ __global__ void narrow_assign_u8(const int *__restrict__ a, long long n, uint8_t
 // ---------------------------------------------------------------------------
 constexpr int SORT_ROWS_PER_WAVE = 2048;
 
+// All update kernels take an array of per-problem descriptors and pick theirs with
+// blockIdx.y (z for the group scan), so the m sub-quantizers of a ProductQuantizer are
+// updated by ONE launch each: the sequential chains are latency-bound (k*s threads per
+// problem), and only running all problems' chains side by side fills the GPU.
+
 // per wave-chunk histogram: hist[chunk][k]
-__global__ __launch_bounds__(256) void sort_hist(const int *__restrict__ assign, int n, int k,
-                                                 unsigned *__restrict__ hist) {
+__global__ __launch_bounds__(256) void sort_hist(const UpdDesc *__restrict__ descs, int n, int k) {
+  const UpdDesc D = descs[blockIdx.y];
   extern __shared__ unsigned sh[];  // 4 * k
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned *h = sh + wave * k;
@@ -255,56 +271,52 @@ __global__ __launch_bounds__(256) void sort_hist(const int *__restrict__ assign,
   long long chunk = (long long)blockIdx.x * 4 + wave;
   long long r0 = chunk * SORT_ROWS_PER_WAVE;
   long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
-  for (long long r = r0 + lane; r < r1; r += 64) atomicAdd(&h[assign[r]], 1u);
+  for (long long r = r0 + lane; r < r1; r += 64) atomicAdd(&h[D.assign[r]], 1u);
   if (r0 < n)
-    for (int c = lane; c < k; c += 64) hist[(size_t)chunk * k + c] = h[c];
+    for (int c = lane; c < k; c += 64) D.hist[(size_t)chunk * k + c] = h[c];
 }
 
 // two-level exclusive scan of the per-chunk histograms (per cluster, over chunks):
 // level 1: one thread per (group of SCAN_GROUP chunks, cluster) scans its chunks in place
 constexpr int SCAN_GROUP = 64;
-__global__ void sort_scan_groups(unsigned *__restrict__ hist, long long nchunks, int k,
-                                 unsigned *__restrict__ gtot) {
+__global__ void sort_scan_groups(const UpdDesc *__restrict__ descs, long long nchunks, int k) {
+  const UpdDesc D = descs[blockIdx.z];
   int c = blockIdx.y * blockDim.x + threadIdx.x;
   long long g = blockIdx.x;
   if (c >= k) return;
   long long c0 = g * SCAN_GROUP, c1 = c0 + SCAN_GROUP < nchunks ? c0 + SCAN_GROUP : nchunks;
   unsigned run = 0;
   for (long long ch = c0; ch < c1; ch++) {
-    unsigned v = hist[(size_t)ch * k + c];
-    hist[(size_t)ch * k + c] = run;
+    unsigned v = D.hist[(size_t)ch * k + c];
+    D.hist[(size_t)ch * k + c] = run;
     run += v;
   }
-  gtot[(size_t)g * k + c] = run;
+  D.gtot[(size_t)g * k + c] = run;
 }
 // level 2: one thread per cluster scans the group totals; then cluster starts
-__global__ void sort_scan_top(unsigned *__restrict__ gtot, long long ngroups, int k, unsigned *__restrict__ count,
-                              unsigned *__restrict__ start) {
+__global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngroups, int k) {
+  const UpdDesc D = descs[blockIdx.y];
   extern __shared__ unsigned cnt[];  // k
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
     unsigned run = 0;
     for (long long g = 0; g < ngroups; g++) {
-      unsigned v = gtot[(size_t)g * k + c];
-      gtot[(size_t)g * k + c] = run;
+      unsigned v = D.gtot[(size_t)g * k + c];
+      D.gtot[(size_t)g * k + c] = run;
       run += v;
     }
     cnt[c] = run;
-    count[c] = run;
+    D.count[c] = run;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned run = 0;
-    for (int c = 0; c < k; c++) { start[c] = run; run += cnt[c]; }
+    for (int c = 0; c < k; c++) { D.start[c] = run; run += cnt[c]; }
   }
 }
 
-// each wave places its chunk's rows in order and copies their column slice to the
-// cluster-sorted buffer: sorted[(start[c] + rank) * s + j] = X[row][from + j]
-__global__ __launch_bounds__(256) void sort_place(const int *__restrict__ assign, int n, int k,
-                                                  const unsigned *__restrict__ hist,
-                                                  const unsigned *__restrict__ gtot,
-                                                  const unsigned *__restrict__ start, const float *__restrict__ X,
-                                                  int ld, int from, int s, float *__restrict__ sorted) {
+// each wave places its chunk's rows in order: order[start[c] + rank] = row (stable)
+__global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k) {
+  const UpdDesc D = descs[blockIdx.y];
   extern __shared__ unsigned sh[];  // 4 * k running positions
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned *run = sh + wave * k;
@@ -313,58 +325,72 @@ __global__ __launch_bounds__(256) void sort_place(const int *__restrict__ assign
   if (r0 >= n) return;
   long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
   const long long grp = chunk / SCAN_GROUP;
-  for (int c = lane; c < k; c += 64) run[c] = start[c] + gtot[(size_t)grp * k + c] + hist[(size_t)chunk * k + c];
+  for (int c = lane; c < k; c += 64)
+    run[c] = D.start[c] + D.gtot[(size_t)grp * k + c] + D.hist[(size_t)chunk * k + c];
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (long long base = r0; base < r1; base += 64) {
     long long r = base + lane;
     bool valid = r < r1;
-    int key = valid ? assign[r] : -1;
-    unsigned pos = 0;
+    int key = valid ? D.assign[r] : -1;
     unsigned long long todo = __ballot(valid);
     while (todo) {
       int l = __ffsll((long long)todo) - 1;
       int k0 = __builtin_amdgcn_readlane(key, l);
       unsigned long long mk = __ballot(valid && key == k0);
       unsigned b = run[k0];                      // wave-uniform read
-      if (valid && key == k0) pos = b + __popcll(mk & lt);
+      if (valid && key == k0) D.order[b + __popcll(mk & lt)] = (int)r;
       if (lane == l) run[k0] = b + __popcll(mk);
       todo &= ~mk;
-    }
-    if (valid) {
-      const float *src = X + (size_t)r * ld + from;
-      float *dst = sorted + (size_t)pos * s;
-      for (int j = 0; j < s; j++) dst[j] = src[j];
     }
   }
 }
 
 // one thread per (cluster, dim): c_j <- c_j + (x_j - c_j)/n over the cluster's rows
 // in row order (KMeans.scala:211-224).  IEEE division (__fdiv_rn), int->float RNE.
-// The rows of a cluster are contiguous in `sorted`, so the loads do not depend on the
-// chain and are issued U steps ahead of the sequential divide-add recurrence.
-__global__ __launch_bounds__(64) void update_chains(const float *__restrict__ sorted, int s, int k,
-                                                    const unsigned *__restrict__ count,
-                                                    const unsigned *__restrict__ start, float *__restrict__ C) {
+// Two-level software pipeline: row ids two batches ahead, row values one batch ahead of the
+// sequential divide-add recurrence (neither load depends on the chain).
+__global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ descs, int k) {
+  const UpdDesc D = descs[blockIdx.y];
+  const int s = D.s;
+  const float *__restrict__ X = D.x;
+  const int ld = D.ld;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k * s) return;
   int c = t / s, j = t - c * s;
-  const unsigned len = count[c];
-  const float *col = sorted + (size_t)start[c] * s + j;
+  const unsigned len = D.count[c];
+  const int *ord = D.order + D.start[c];
+  const float *col = X + D.from + j;
   float p = 0.f;
-  unsigned i = 0;
+  if (len == 0) { D.cout[t] = 0.f; return; }
   constexpr int U = 16;
-  for (; i + U <= len; i += U) {
-    float xv[U];
+  const unsigned nb = len / U;          // full batches
+  const unsigned last = len - 1;
+  // every prefetch index is clamped to the last row of the cluster, so the loads are
+  // unconditional: a select-or-load per element makes hipcc branch around each load and
+  // wait for it individually (one exposed memory latency per step)
+  int o1[U];
+  float xa[U], xb[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) xv[u] = col[(size_t)(i + u) * s];
+  for (int u = 0; u < U; u++) xa[u] = col[(size_t)ord[min((unsigned)u, last)] * ld];
 #pragma unroll
-    for (int u = 0; u < U; u++) p = p + __fdiv_rn(xv[u] - p, (float)(int)(i + u + 1));
+  for (int u = 0; u < U; u++) o1[u] = ord[min((unsigned)(U + u), last)];
+  unsigned i = 0;
+  for (unsigned b = 0; b < nb; b++) {
+#pragma unroll
+    for (int u = 0; u < U; u++) xb[u] = col[(size_t)o1[u] * ld];
+#pragma unroll
+    for (int u = 0; u < U; u++) o1[u] = ord[min(i + 2 * U + u, last)];
+#pragma unroll
+    for (int u = 0; u < U; u++) p = p + __fdiv_rn(xa[u] - p, (float)(int)(i + u + 1));
+#pragma unroll
+    for (int u = 0; u < U; u++) xa[u] = xb[u];
+    i += U;
   }
   for (; i < len; i++) {
-    float xv = col[(size_t)i * s];
+    float xv = col[(size_t)ord[i] * ld];
     p = p + __fdiv_rn(xv - p, (float)(int)(i + 1));
   }
-  C[t] = p;
+  D.cout[t] = p;
 }
 
 // ---------------------------------------------------------------------------
@@ -396,7 +422,7 @@ void KmeansWorkspace::ensure(int n, int k, int s) {
   gtot.ensure((size_t)ceil_div(nchunks_pad, SCAN_GROUP) * k);
   count.ensure(k);
   start.ensure(k);
-  sorted.ensure((size_t)std::max(n, 1) * std::max(s, 1));
+  order.ensure((size_t)std::max(n, 1));
   mismatch.ensure(1);
 }
 
@@ -515,28 +541,49 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
   if (!j.done) { HIP_CHECK(hipStreamSynchronize(st)); assign_stage3(j); }
 }
 
-// KMeans.fromAssignment on device arrays -> dC (k x s)
-void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
-                       const int *d_assign, float *dC, hipStream_t st) {
-  ws.ensure(n, k, s);
+// KMeans.fromAssignment for a batch of problems over the same data -> each D.cout (k x s).
+// `d_descs` must hold descs.size() entries of device memory.
+void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st) {
+  const int np = (int)descs.size();
+  if (np == 0) return;
   if (n <= 0) {
-    HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(float) * (size_t)k * s, st));
+    for (const UpdDesc &D : descs) HIP_CHECK(hipMemsetAsync(D.cout, 0, sizeof(float) * (size_t)k * D.s, st));
     return;
   }
+  HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
+  int smax = 1;
+  for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
   long long nchunks = ceil_div(n, SORT_ROWS_PER_WAVE);
   int blocks = ceil_div(nchunks, 4);
   long long ngroups = ceil_div(nchunks, SCAN_GROUP);
   size_t shm = sizeof(unsigned) * 4 * (size_t)k;
-  hipLaunchKernelGGL(sort_hist, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p);
-  hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256)), dim3(256), 0, st, ws.hist.p, nchunks,
-                     k, ws.gtot.p);
-  hipLaunchKernelGGL(sort_scan_top, dim3(1), dim3(256), sizeof(unsigned) * (size_t)k, st, ws.gtot.p, ngroups, k,
-                     ws.count.p, ws.start.p);
-  hipLaunchKernelGGL(sort_place, dim3(blocks), dim3(256), shm, st, d_assign, n, k, ws.hist.p, ws.gtot.p, ws.start.p,
-                     dX, ld, from, s, ws.sorted.p);
-  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * s, 64)), dim3(64), 0, st, ws.sorted.p, s, k,
-                     ws.count.p, ws.start.p, dC);
+  hipLaunchKernelGGL(sort_hist, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k);
+  hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256), np), dim3(256), 0, st, d_descs,
+                     nchunks, k);
+  hipLaunchKernelGGL(sort_scan_top, dim3(1, np), dim3(256), sizeof(unsigned) * (size_t)k, st, d_descs, ngroups, k);
+  hipLaunchKernelGGL(sort_place, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k);
+  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * smax, 64), np), dim3(64), 0, st, d_descs, k);
   HIP_CHECK(hipGetLastError());
+}
+
+// x/ld/from describe where row r's slice starts: x + r*ld + from
+UpdDesc make_upd_desc(KmeansWorkspace &ws, const float *x, int ld, int n, int k, int from, int s, const int *d_assign,
+                      float *dC) {
+  ws.ensure(n, k, s);
+  UpdDesc D;
+  D.x = x; D.ld = ld;
+  D.assign = d_assign; D.hist = ws.hist.p; D.gtot = ws.gtot.p; D.count = ws.count.p; D.start = ws.start.p;
+  D.order = ws.order.p; D.cout = dC; D.from = from; D.s = s;
+  return D;
+}
+
+// single-problem form
+void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
+                       const int *d_assign, float *dC, hipStream_t st) {
+  std::vector<UpdDesc> descs{make_upd_desc(ws, dX, ld, n, k, from, s, d_assign, dC)};
+  ws.descs.ensure(1);
+  kmeans_update_batch(descs, ws.descs.p, n, k, st);
+  // descs is read by hipMemcpyAsync from pageable memory: staged before the call returns
 }
 
 static void validate_assignments(const int32_t *a, int n, int k) {
@@ -575,6 +622,16 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
                         int k, int max_iterations, float *const *c_out, gulon_kmeans_report *reports,
                         int max_reports, int32_t *n_reports) {
   GULON_REQUIRE(n >= 1, "KMeans.init needs at least one row (n = %d)", n);   // rng.nextInt(0) throws on the JVM
+  const bool trace = getenv("GULON_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](const char *what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    double t = now();
+    fprintf(stderr, "[gulon trace] %-28s %8.2f ms\n", what, t - t_mark);
+    t_mark = t;
+  };
   struct Prob {
     KmeansWorkspace ws;
     hipStream_t st = nullptr;
@@ -583,6 +640,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     DevBuf<unsigned> mism;
     std::vector<float> h_prev, h_next;
     PackedSlice packed;      // MFMA-ready copy of this problem's column slice
+    DevBuf<float> xs;        // row-major n x s copy of the slice: compact target of the update's gathers
     AssignJob job;
     bool use_mfma = false;
     bool done = false;
@@ -612,6 +670,15 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     }
   };
 
+  DevBuf<UpdDesc> d_descs(np);
+  hipStream_t bst = nullptr;
+  hipEvent_t upd_done = nullptr;
+  HIP_CHECK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&upd_done, hipEventDisableTiming));
+  struct Cleanup {
+    hipStream_t &s; hipEvent_t &e;
+    ~Cleanup() { if (e) (void)hipEventDestroy(e); if (s) (void)hipStreamDestroy(s); }
+  } cleanup{bst, upd_done};
   std::vector<int> all(np);
   for (int p = 0; p < np; p++) {
     all[p] = p;
@@ -634,28 +701,42 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, pr.st));
     pr.use_mfma = mfma_assign_supported(s, k);
     if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, pr.st);
+    pr.xs.alloc((size_t)n * s);
+    hipLaunchKernelGGL(copy_slice, dim3(ceil_div((long long)n * s, 256)), dim3(256), 0, pr.st, dX, ld, from[p], s,
+                       (long long)n * s, pr.xs.p);
     make_job(p, pr.c_prev.p, pr.a_prev.p);
     assign_stage1(pr.job);
     push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
   }
+  lap("alloc+pack+stage1");
   finish_assigns(all);
   for (int p = 0; p < np; p++) {
     P[p].c_prev.download(P[p].h_prev.data(), (size_t)k * sdim[p], P[p].st);
     HIP_CHECK(hipStreamSynchronize(P[p].st));
   }
+  lap("first assign done");
 
   for (int i = 0; i <= max_iterations;) {
     std::vector<int> act;
     for (int p = 0; p < np; p++) if (!P[p].done) act.push_back(p);
     if (act.empty()) break;
+    // one batched update for all active problems, then every problem's assign on its own stream
+    std::vector<UpdDesc> descs;
+    for (int p : act)
+      descs.push_back(make_upd_desc(P[p].ws, P[p].xs.p, sdim[p], n, k, 0, sdim[p], P[p].a_prev.p, P[p].c_next.p));
+    kmeans_update_batch(descs, d_descs.p, n, k, bst);
+    HIP_CHECK(hipEventRecord(upd_done, bst));
+    lap("  update batch");
     for (int p : act) {
       Prob &pr = P[p];
-      kmeans_update_dev(pr.ws, dX, n, ld, from[p], sdim[p], k, pr.a_prev.p, pr.c_next.p, pr.st);
+      HIP_CHECK(hipStreamWaitEvent(pr.st, upd_done, 0));
       HIP_CHECK(hipMemsetAsync(pr.a_next.p, 0, sizeof(int) * (size_t)n, pr.st));   // fresh Array[Int] per parAssign
       make_job(p, pr.c_next.p, pr.a_next.p);
       assign_stage1(pr.job);
     }
+    lap("  assign stage1");
     finish_assigns(act);
+    lap("  assign stages 2-3");
     std::vector<unsigned> h_mism(np, 0);
     for (int p : act) {
       Prob &pr = P[p];
@@ -678,6 +759,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
       std::swap(pr.h_prev, pr.h_next);
       if (converged) pr.done = true; else all_conv = false;
     }
+    lap("  mismatch+reports");
     if (all_conv) break;
     i++;
   }

@@ -13,6 +13,16 @@ struct PackedSlice {
   int n = 0, from = 0, s = 0, T = 0;
 };
 
+// one problem of a batched KMeans.fromAssignment (kmeans.hip)
+struct UpdDesc {
+  const int *assign;
+  unsigned *hist, *gtot, *count, *start;
+  int *order;
+  float *cout;
+  const float *x;   // row r's slice = x + r*ld + from
+  int ld, from, s;
+};
+
 struct KmeansWorkspace {
   struct HostWords { unsigned flagged; unsigned pad; unsigned long long total; };
   HostWords *host = nullptr;           // pinned: counters copied back asynchronously
@@ -24,7 +34,8 @@ struct KmeansWorkspace {
   DevBuf<unsigned> ties, local, block_tot;
   DevBuf<unsigned long long> tie_total, block_off;
   DevBuf<unsigned> hist, gtot, count, start, mismatch;
-  DevBuf<float> sorted;                // column slice of the rows, grouped by cluster (stable)
+  DevBuf<int> order;                   // rows grouped by cluster, stable (row order inside a cluster)
+  DevBuf<UpdDesc> descs;
   // MFMA filter
   DevBuf<float> apack, offp;
   DevBuf<unsigned> cmax2, flag_count, flag_ties;

@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gulon_amd as g
 from gulon_amd import native as N
 
