@@ -65,8 +65,12 @@ __global__ __launch_bounds__(64) void rp_seg_scan(const uint8_t *__restrict__ co
                                                   int *__restrict__ evcnt, int *__restrict__ overflow) {
   using Word = typename RpWord<VEC>::type;
   extern __shared__ float tab[];   // m_pad * 256
-  const int f = blockIdx.y, s = blockIdx.x, lane = threadIdx.x;
-  if (f >= min(*count, maxf)) return;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int nf = min(*count, maxf);
+  // the grid has a fixed, small y extent; each block walks the flagged queries f = y, y+Y, ...
+  // (an empty launch then costs a few thousand blocks instead of nseg * maxf)
+  for (int f = blockIdx.y; f < nf; f += gridDim.y) {
+  __syncthreads();
   {
     const float *src = tables + (size_t)f * m_pad * 256;
     for (int e = lane; e < m_pad * 256; e += 64) tab[e] = src[e];
@@ -121,14 +125,16 @@ __global__ __launch_bounds__(64) void rp_seg_scan(const uint8_t *__restrict__ co
   } else if (lane == 0) {
     evcnt[fs] = min(nev, evcap);
   }
+  }
 }
 
 // exclusive prefix over segments of "the K smallest distances so far"; one wave per query
 __global__ __launch_bounds__(64) void rp_prefix(const float *__restrict__ segtop, const int *__restrict__ segcnt,
                                                 const int *__restrict__ count, int maxf, int nseg, int K,
                                                 float *__restrict__ prefix, int *__restrict__ precnt) {
-  const int f = blockIdx.x, lane = threadIdx.x;
-  if (f >= min(*count, maxf)) return;
+  const int lane = threadIdx.x;
+  const int nf = min(*count, maxf);
+  for (int f = blockIdx.x; f < nf; f += gridDim.x) {
   WaveList wl;
   wl.init();
   int cnt = 0;
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(64) void rp_prefix(const float *__restrict__ segtop
       }
     }
   }
+  }
 }
 
 // literal TopKHeap (TopKHeap.scala) over the events, then Result.fromHeap (Index.scala:83-94)
@@ -154,9 +161,9 @@ __global__ void rp_heap(const float *__restrict__ evv, const int *__restrict__ e
                         const int *__restrict__ overflow, const int *__restrict__ list,
                         const int *__restrict__ count, int maxf, int nseg, int evcap, int K, int *__restrict__ out_idx,
                         float *__restrict__ out_dist, int *__restrict__ out_count, int *__restrict__ out_flags) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= min(*count, maxf)) return;
-  if (overflow[f]) return;   // keeps the (distance, row id) result and its tie flags
+  const int nf = min(*count, maxf);
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+  if (overflow[f]) continue;   // keeps the (distance, row id) result and its tie flags
   int keys[GULON_MAX_K];
   float vals[GULON_MAX_K];
   int size = 0;
@@ -210,6 +217,7 @@ __global__ void rp_heap(const float *__restrict__ evv, const int *__restrict__ e
   for (int i = live; i < K; i++) { out_idx[(size_t)q * K + i] = -1; out_dist[(size_t)q * K + i] = INFINITY; }
   if (out_count) out_count[q] = live;
   out_flags[q] |= GULON_FLAG_EXACT_REPLAY;
+  }
 }
 
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
@@ -217,7 +225,8 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
   if (B <= 0 || K <= 0 || until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
   const int maxf = std::min(B, RP_MAXF);
-  int nseg = std::min(maxf <= 64 ? RP_MAXSEG : 128, std::max(1, rb_total / 4));
+  int nseg = std::min(maxf <= 64 ? RP_MAXSEG : 256, std::max(1, rb_total / 4));
+  const int gy = std::min(maxf, 16);   // y extent of the segment-scan grids
   const int rb_per_seg = ceil_div(rb_total, nseg);
   nseg = ceil_div(rb_total, rb_per_seg);
   const int evcap = 64 + 8 * K;
@@ -241,17 +250,17 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
     auto kern = rp_seg_scan<V, PH>;                                                                                \
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds));                                                                      \
-    hipLaunchKernelGGL(kern, dim3(nseg, maxf), dim3(64), lds, st, ix->codes.p, ix->ng, ix->m_pad,                  \
+    hipLaunchKernelGGL(kern, dim3(nseg, gy), dim3(64), lds, st, ix->codes.p, ix->ng, ix->m_pad,                  \
                        ix->rp_tables.p, ix->rp_count.p, maxf, from, until, ix->row_base, rb_begin, rb_end, rb_per_seg,   \
                        nseg, K, ix->rp_segtop.p, ix->rp_segcnt.p, ix->rp_prefix.p, ix->rp_precnt.p, evcap,          \
                        ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p, ix->rp_overflow.p);                             \
   } while (0)
   if (ix->vec == 16) SEG(16, 0); else SEG(4, 0);
-  hipLaunchKernelGGL(rp_prefix, dim3(maxf), dim3(64), 0, st, ix->rp_segtop.p, ix->rp_segcnt.p, ix->rp_count.p,
+  hipLaunchKernelGGL(rp_prefix, dim3(std::min(maxf, 64)), dim3(64), 0, st, ix->rp_segtop.p, ix->rp_segcnt.p, ix->rp_count.p,
                      maxf, nseg, K, ix->rp_prefix.p, ix->rp_precnt.p);
   if (ix->vec == 16) SEG(16, 1); else SEG(4, 1);
 #undef SEG
-  hipLaunchKernelGGL(rp_heap, dim3(ceil_div(maxf, 64)), dim3(64), 0, st, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p,
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(ceil_div(maxf, 64), 4)), dim3(64), 0, st, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p,
                      ix->rp_overflow.p, ix->rp_list.p, ix->rp_count.p, maxf, nseg, evcap, K, d_oi, d_od, d_oc, d_of);
   HIP_CHECK(hipGetLastError());
 }
