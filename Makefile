@@ -12,7 +12,7 @@ SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip 
 OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.h
 
-all: $(LIB) oracle
+all: $(LIB) oracle build/test_host_api
 
 # MFMA results are consumed by VALU/permlane code: keep accumulators in VGPRs (no v_accvgpr moves)
 $(OBJDIR)/kmeans_mfma.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
@@ -27,6 +27,12 @@ $(LIB): $(OBJS)
 
 oracle:
 	$(MAKE) -C oracle
+
+# C++ host-API parity test (tests/cpp): gulon.hpp over the C ABI, checked against the oracle
+build/test_host_api: tests/cpp/test_host_api.cpp include/gulon/gulon.hpp include/gulon_hip.h $(LIB) oracle
+	@mkdir -p build
+	g++ -O2 -std=c++17 -Iinclude tests/cpp/test_host_api.cpp -o $@ -Lgulon_amd/lib -lgulon_hip -Loracle/build -lgulon_oracle \
+	    -Wl,-rpath,'$$ORIGIN/../gulon_amd/lib' -Wl,-rpath,'$$ORIGIN/../oracle/build'
 
 clean:
 	rm -rf build $(LIB)

@@ -32,9 +32,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--d", type=int, default=128)
-    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--rows", type=int, default=10_000_000)   # (not --n/--m/--d: torchrun would read them as its own)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--quantizers", type=int, default=16)
     ap.add_argument("--clusters", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--knn", type=int, default=10)
@@ -54,6 +54,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "GULON_BENCH_DEVICE" in os.environ:        # debugging aid: put every rank on one device
+        local_rank = int(os.environ["GULON_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
@@ -63,10 +65,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("GULON_BENCH_BACKEND") == "gloo":   # rehearsal of the multi-rank path on one GPU
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     L = N.lib()
-    n, d, m, k, B, K = args.n, args.d, args.m, args.clusters, args.batch, args.knn
+    n, d, m, k, B, K = args.rows, args.dim, args.quantizers, args.clusters, args.batch, args.knn
 
     # ---- untimed build: synthetic clustered data -> PQ train -> encode (all on the GPU) -----
     t0 = time.perf_counter()
@@ -111,7 +116,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     ms_total, launches = C.c_double(0), C.c_int32(0)

@@ -77,6 +77,10 @@ class ShardedIndex:
         self.n_total, self.rank, self.world, self.dist = n_total, rank, world, dist
         self.lo, self.hi = shard_bounds(n_total, world, rank)
         self._bufs = {}
+        # RCCL gathers device tensors directly; a gloo group (CPU rehearsal of the multi-rank path
+        # with the real HIP engine) needs the lists staged through the host
+        self.host_staged = bool(dist is not None and world > 1 and dist.get_backend() == "gloo"
+                                and getattr(engine, "device", None) is not None)
 
     def _buffers(self, b, k):
         key = (b, k)
@@ -96,8 +100,17 @@ class ShardedIndex:
             self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
         else:
             self.engine.scan_partial(q, b, k, u["pv"], u["pi"])
-            self.dist.all_gather_into_tensor(u["av"], u["pv"])
-            self.dist.all_gather_into_tensor(u["ai"], u["pi"])
+            if self.host_staged:
+                # rehearsal path (gloo has no device collectives): same layout, staged through the host
+                hv, hi = u["pv"].cpu(), u["pi"].cpu()
+                gv, gi = u["av"].cpu(), u["ai"].cpu()
+                self.dist.all_gather_into_tensor(gv, hv)
+                self.dist.all_gather_into_tensor(gi, hi)
+                u["av"].copy_(gv)
+                u["ai"].copy_(gi)
+            else:
+                self.dist.all_gather_into_tensor(u["av"], u["pv"])
+                self.dist.all_gather_into_tensor(u["ai"], u["pi"])
             self.engine.merge(u["av"], u["ai"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
         return u["oi"], u["od"], u["oc"], u["of"]
 
