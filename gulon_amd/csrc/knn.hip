@@ -25,7 +25,8 @@ __global__ void transpose_queries(const float *__restrict__ Q, int B, int d, int
 __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float *__restrict__ X, int n, int d,
                                                           const float *__restrict__ Qt, int row_from, int row_until,
                                                           int rows_per_chunk, int nchunks, int keff,
-                                                          float *__restrict__ part_v, int *__restrict__ part_i) {
+                                                          float *__restrict__ part_v, int *__restrict__ part_i,
+                                                          const float *__restrict__ lbv, const int *__restrict__ lbi) {
   constexpr int NW = KNN_THREADS / 64;
   __shared__ float xs[KNN_THREADS * (KNN_DT + 1)];
   __shared__ float sv[KNN_QT * NW * 64];
@@ -38,6 +39,16 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float *__restric
   int cnt[KNN_QT];
 #pragma unroll
   for (int q = 0; q < KNN_QT; q++) { wl[q].init(); cnt[q] = 0; }
+
+  // large-K peeling: only entries after (lbq, lbiq) in (distance, row id) order are eligible
+  const bool peel = lbv != nullptr;
+  float lbq[KNN_QT];
+  int lbiq[KNN_QT];
+#pragma unroll
+  for (int q = 0; q < KNN_QT; q++) {
+    lbq[q] = peel ? lbv[tile * KNN_QT + q] : -1.f;
+    lbiq[q] = peel ? lbi[tile * KNN_QT + q] : -1;
+  }
 
   const int r0 = (row_from / KNN_THREADS) * KNN_THREADS + chunk * rows_per_chunk;
   const int r1 = min(row_until, r0 + rows_per_chunk);
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float *__restric
         mk &= mk - 1;
         float cv = readlane_f(acc[q], l);
         int cr = base + wave * 64 + l;
+        if (peel && !(cv > lbq[q] || (cv == lbq[q] && cr > lbiq[q]))) continue;
         if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
           wl[q].insert(cv, cr, keff, lane);
           if (cnt[q] < keff) cnt[q]++;
@@ -122,9 +134,10 @@ GULON_API int32_t gulon_exact_knn(const gulon_dataset *ds, int32_t from, int32_t
     GULON_REQUIRE(from <= until, "invalid range: expected from=%d <= until=%d", from, until);          // Index.scala:213
     GULON_REQUIRE(until <= ds->n, "invalid range: expected until=%d <= vectors.length=%d", until, ds->n);  // :214
     GULON_REQUIRE(from >= 0 && b >= 0 && k_nn >= 0, "bad arguments");
-    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K_PEELED, "k_nn = %d > %d", k_nn, GULON_MAX_K_PEELED);
     if (b == 0) return;
-    const int K = k_nn, keff = K + 1, d = ds->d;
+    const bool peeled = k_nn > GULON_MAX_K;
+    const int K = k_nn, keff = peeled ? 64 : K + 1, d = ds->d;
     size_t bk = (size_t)b * K;
     if (K == 0 || from == until) {
       for (size_t i = 0; i < bk; i++) { out_idx[i] = -1; out_dist[i] = INFINITY; }
@@ -146,11 +159,30 @@ GULON_API int32_t gulon_exact_knn(const gulon_dataset *ds, int32_t from, int32_t
     dq.upload(queries, (size_t)b * d);
     long long tq = (long long)ntiles * d * KNN_QT;
     hipLaunchKernelGGL(transpose_queries, dim3(ceil_div(tq, 256)), dim3(256), 0, 0, dq.p, b, d, ntiles, dqt.p);
-    hipLaunchKernelGGL(knn_kernel, dim3(ntiles, nchunks), dim3(KNN_THREADS), 0, 0, ds->x.p, ds->n, d, dqt.p, from,
-                       until, rows_per_chunk, nchunks, keff, pv.p, pi.p);
-    HIP_CHECK(hipGetLastError());
-    launch_merge(true, pv.p, pi.p, nchunks, (long long)keff, (long long)nchunks * keff, b, K, oi.p, od.p, oc.p, of.p,
-                 nullptr, nullptr, nullptr);
+    if (peeled) {
+      const int rounds = ceil_div(K + 1, 64), cap = rounds * 64;
+      DevBuf<float> acc_v((size_t)b * cap), tv((size_t)b * 64), lbv(Bp);
+      DevBuf<int> acc_i((size_t)b * cap), ti((size_t)b * 64), lbi(Bp);
+      HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)lbv.p, 0xBF800000 /* -1.0f */, (size_t)Bp, 0));
+      HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)lbi.p, 0xFFFFFFFF, (size_t)Bp, 0));
+      for (int r = 0; r < rounds; r++) {
+        hipLaunchKernelGGL(knn_kernel, dim3(ntiles, nchunks), dim3(KNN_THREADS), 0, 0, ds->x.p, ds->n, d, dqt.p, from,
+                           until, rows_per_chunk, nchunks, 64, pv.p, pi.p, lbv.p, lbi.p);
+        HIP_CHECK(hipGetLastError());
+        launch_merge(false, pv.p, pi.p, nchunks, 64LL, (long long)nchunks * 64, b, 63, nullptr, nullptr, nullptr,
+                     nullptr, tv.p, ti.p, nullptr);
+        launch_peel_update(tv.p, ti.p, b, r, cap, acc_v.p, acc_i.p, lbv.p, lbi.p, nullptr);
+      }
+      launch_peel_finalize(acc_v.p, acc_i.p, b, cap, K, oi.p, od.p, oc.p, of.p, nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+    } else {
+      hipLaunchKernelGGL(knn_kernel, dim3(ntiles, nchunks), dim3(KNN_THREADS), 0, 0, ds->x.p, ds->n, d, dqt.p, from,
+                         until, rows_per_chunk, nchunks, keff, pv.p, pi.p, (const float *)nullptr,
+                         (const int *)nullptr);
+      HIP_CHECK(hipGetLastError());
+      launch_merge(true, pv.p, pi.p, nchunks, (long long)keff, (long long)nchunks * keff, b, K, oi.p, od.p, oc.p,
+                   of.p, nullptr, nullptr, nullptr);
+    }
     oi.download(out_idx, bk); od.download(out_dist, bk);
     if (out_count) oc.download(out_count, b);
     if (out_flags) of.download(out_flags, b);

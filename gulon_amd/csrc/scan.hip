@@ -136,7 +136,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
     int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
-    int prune_from) {
+    int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi) {
   constexpr int QT = W * NSUB;
   constexpr int NW = THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
@@ -171,6 +171,17 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   int cnt[QT];
 #pragma unroll
   for (int q = 0; q < QT; q++) { wl[q].init(); cnt[q] = 0; }
+
+  // large-K "peeling" rounds: only entries strictly after (lbq, lbiq) in (distance, row id)
+  // order are eligible (the earlier ones were returned by previous rounds)
+  const bool peel = lbv != nullptr;
+  float lbq[QT];
+  int lbiq[QT];
+#pragma unroll
+  for (int q = 0; q < QT; q++) {
+    lbq[q] = peel ? lbv[tile * QT + q] : -1.f;
+    lbiq[q] = peel ? lbi[tile * QT + q] : -1;
+  }
 
   const int rb0 = rb_begin + chunk * rb_per_chunk;
   const int rb1 = min(rb_end, rb0 + rb_per_chunk);
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
           mk &= mk - 1;
           float cv = readlane_f(acc[q], l);
           int cr = rb * 64 + l + row_base;
+          if (peel && !(cv > lbq[q] || (cv == lbq[q] && cr > lbiq[q]))) continue;
           if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
             wl[q].insert(cv, cr, keff, lane);
             if (cnt[q] < keff) cnt[q]++;
@@ -395,6 +407,54 @@ void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists,
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- large K: peel the result 64 entries at a time (each round = one scan restricted to the
+// ---- entries after the previous round's last one) -------------------------------------
+__global__ __launch_bounds__(64) void peel_update(const float *__restrict__ tv, const int *__restrict__ ti, int round,
+                                                  int cap, float *__restrict__ pv, int *__restrict__ pi,
+                                                  float *__restrict__ lbv, int *__restrict__ lbi) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const float v = tv[(size_t)q * 64 + lane];
+  const int i = ti[(size_t)q * 64 + lane];
+  pv[(size_t)q * cap + round * 64 + lane] = v;
+  pi[(size_t)q * cap + round * 64 + lane] = i;
+  if (lane == 63) {
+    if (i != INT_MAX) { lbv[q] = v; lbi[q] = i; }
+    else { lbv[q] = INFINITY; lbi[q] = INT_MAX; }   // list exhausted: nothing is eligible any more
+  }
+}
+
+__global__ void peel_finalize(const float *__restrict__ pv, const int *__restrict__ pi, int B, int cap, int K,
+                              int *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ out_count,
+                              int *__restrict__ out_flags) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= B) return;
+  const float *v = pv + (size_t)q * cap;
+  const int *id = pi + (size_t)q * cap;
+  int live = 0, flags = 0;
+  for (int e = 0; e < K; e++) {
+    const bool ok = id[e] != INT_MAX;
+    out_idx[(size_t)q * K + e] = ok ? id[e] : -1;
+    out_dist[(size_t)q * K + e] = ok ? v[e] : INFINITY;
+    live += ok ? 1 : 0;
+    if (ok && e + 1 < cap && id[e + 1] != INT_MAX && v[e] == v[e + 1])
+      flags |= (e == K - 1) ? GULON_FLAG_BOUNDARY_TIE : GULON_FLAG_INTERIOR_TIE;
+  }
+  if (out_count) out_count[q] = live;
+  if (out_flags) out_flags[q] = flags;
+}
+
+void launch_peel_update(const float *tv, const int *ti, int B, int round, int cap, float *pv, int *pi, float *lbv,
+                        int *lbi, hipStream_t st) {
+  hipLaunchKernelGGL(peel_update, dim3(B), dim3(64), 0, st, tv, ti, round, cap, pv, pi, lbv, lbi);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_peel_finalize(const float *pv, const int *pi, int B, int cap, int K, int *out_idx, float *out_dist,
+                          int *out_count, int *out_flags, hipStream_t st) {
+  hipLaunchKernelGGL(peel_finalize, dim3(ceil_div(B, 64)), dim3(64), 0, st, pv, pi, B, cap, K, out_idx, out_dist,
+                     out_count, out_flags);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st) {
   long long total = (long long)(Bpad / W) * ix->m_pad * 256;
   if (total <= 0) return;
@@ -438,7 +498,7 @@ static const ScanTuning &tuning() { static ScanTuning t; return t; }
 
 template <int W, int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
 void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                   int until, int keff, hipStream_t st) {
+                   int until, int keff, hipStream_t st, const float *lbv, const int *lbi) {
   size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * W * sizeof(float);
   size_t merge_bytes = (size_t)W * NSUB * (SCAN_THREADS / 64) * 64 * 8;
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
@@ -451,23 +511,27 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, rb_end,
-                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from);
+                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
+                     lbi);
   HIP_CHECK(hipGetLastError());
 }
 
 template <int W, int NSUB, int VEC>
 void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                   int until, int keff, hipStream_t st) {
+                   int until, int keff, hipStream_t st, const float *lbv, const int *lbi) {
   constexpr int TH = 1024;
   if (tuning().prune)
-    launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
+    launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st,
+                                          lbv, lbi);
   else
-    launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
+    launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st,
+                                           lbv, lbi);
 }
 
 void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                 int until, int keff, hipStream_t st) {
-#define GO(WW, NS, V) launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st)
+                 int until, int keff, hipStream_t st, const float *lbv = nullptr, const int *lbi = nullptr) {
+#define GO(WW, NS, V) \
+  launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st, lbv, lbi)
   if (ix->w == 4) {
     if (ix->vec == 16) {
       if (ix->nsub == 4) GO(4, 4, 16); else if (ix->nsub == 2) GO(4, 2, 16); else GO(4, 1, 16);
@@ -488,10 +552,12 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   GULON_REQUIRE(from <= until, "expected: from <= until");                               // Index.scala:418
   GULON_REQUIRE(from >= 0 && until <= ix->n, "expected: from >= 0 && until <= length");  // Index.scala:419
   GULON_REQUIRE(K >= 0 && B >= 0, "k and batch size must be non-negative");
-  GULON_UNSUPPORTED(K > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is not supported by the wavefront top-k", K,
-                    GULON_MAX_K);
+  GULON_UNSUPPORTED(K > GULON_MAX_K_PEELED, "k_nn = %d > %d is not supported", K, GULON_MAX_K_PEELED);
+  GULON_UNSUPPORTED(K > GULON_MAX_K && !final_out,
+                    "k_nn = %d > GULON_MAX_K = %d is only supported for unsharded queries", K, GULON_MAX_K);
   if (B == 0) return;
-  const int keff = K + 1;
+  const bool peeled = K > GULON_MAX_K;            // results come 64 at a time
+  const int keff = peeled ? 64 : K + 1;
   const int W = ix->w;
   const int QT = W * ix->nsub;
   const int ntiles = ceil_div(B, QT);
@@ -529,6 +595,31 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   nchunks = ceil_div(rb_total, rb_per_chunk);
 
   const int Bp = ntiles * QT;
+  if (peeled) {
+    launch_build_tables(W, ix, dQ, B, Bp, (ix->tables.ensure((size_t)Bp * ix->m_pad * 256), ix->tables.p), st);
+    const int rounds = ceil_div(K + 1, 64), cap = rounds * 64;
+    ix->part_v.ensure((size_t)Bp * nchunks * 64);
+    ix->part_i.ensure((size_t)Bp * nchunks * 64);
+    ix->gtau.ensure((size_t)Bp);
+    ix->peel_v.ensure((size_t)B * cap); ix->peel_i.ensure((size_t)B * cap);
+    ix->peel_tv.ensure((size_t)B * 64); ix->peel_ti.ensure((size_t)B * 64);
+    ix->peel_lbv.ensure((size_t)Bp); ix->peel_lbi.ensure((size_t)Bp);
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->peel_lbv.p, 0xBF800000 /* -1.0f */, (size_t)Bp, st));
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->peel_lbi.p, 0xFFFFFFFF /* -1 */, (size_t)Bp, st));
+    for (int r = 0; r < rounds; r++) {
+      HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
+      launch_scan(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, 64, st, ix->peel_lbv.p,
+                  ix->peel_lbi.p);
+      launch_merge(false, ix->part_v.p, ix->part_i.p, nchunks, 64LL, (long long)nchunks * 64, B, 63, nullptr, nullptr,
+                   nullptr, nullptr, ix->peel_tv.p, ix->peel_ti.p, st);
+      hipLaunchKernelGGL(peel_update, dim3(B), dim3(64), 0, st, ix->peel_tv.p, ix->peel_ti.p, r, cap, ix->peel_v.p,
+                         ix->peel_i.p, ix->peel_lbv.p, ix->peel_lbi.p);
+    }
+    hipLaunchKernelGGL(peel_finalize, dim3(ceil_div(B, 64)), dim3(64), 0, st, ix->peel_v.p, ix->peel_i.p, B, cap, K,
+                       d_oi, d_od, d_oc, d_of);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   ix->tables.ensure((size_t)Bp * ix->m_pad * 256);
   ix->part_v.ensure((size_t)Bp * nchunks * keff);
   ix->part_i.ensure((size_t)Bp * nchunks * keff);

@@ -13,6 +13,12 @@ void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists,
                   long long stride_q, int B, int K, int *out_idx, float *out_dist, int *out_count,
                   int *out_flags, float *out_pv, int *out_pi, hipStream_t st);
 bool replay_enabled();
+// large-K peeling helpers (scan.hip): append a 64-entry round to [B][cap] and set the next lower bound;
+// then cut the concatenated list to [B][K] + count + tie flags
+void launch_peel_update(const float *tv, const int *ti, int B, int round, int cap, float *pv, int *pi, float *lbv,
+                        int *lbi, hipStream_t st);
+void launch_peel_finalize(const float *pv, const int *pi, int B, int cap, int K, int *out_idx, float *out_dist,
+                          int *out_count, int *out_flags, hipStream_t st);
 }  // namespace gulon
 
 // PQIndex on the device (opaque to C callers)
@@ -32,6 +38,9 @@ struct gulon_index {
   DevBuf<int> stage_oi, stage_oc, stage_of;
   DevBuf<float> stage_od;
   DevBuf<int> flags_scratch;
+  // large-K peeling rounds
+  DevBuf<float> peel_v, peel_tv, peel_lbv;
+  DevBuf<int> peel_i, peel_ti, peel_lbi;
   // exact tie replay (replay.hip)
   DevBuf<int> rp_list, rp_count, rp_segcnt, rp_evcnt, rp_overflow, rp_evi, rp_precnt;
   DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv;

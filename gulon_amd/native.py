@@ -23,6 +23,7 @@ FLAG_BOUNDARY_TIE = 1
 FLAG_INTERIOR_TIE = 2
 FLAG_EXACT_REPLAY = 4
 MAX_K = 63
+MAX_K_PEELED = 8191
 
 
 class GulonDeviceError(RuntimeError):

@@ -49,7 +49,10 @@ extern "C" {
 #define GULON_FLAG_EXACT_REPLAY 4 /* tie resolved by replaying the reference heap's insertion history:
                                      ids and order are exactly TopKHeap's (single, unsharded index only) */
 
-#define GULON_MAX_K 63 /* neighbours per query supported by the wavefront top-k */
+#define GULON_MAX_K 63 /* neighbours per query held by one wavefront list: fast path, exact tie replay,
+                          sharded merge */
+#define GULON_MAX_K_PEELED 8191 /* larger k_nn (unsharded queries, exact kNN): the result is peeled 64
+                                   entries per scan; ties keep the (distance, row id) order + flags */
 
 typedef struct gulon_dataset gulon_dataset; /* device-resident Matrix            */
 typedef struct gulon_index gulon_index;     /* device-resident PQIndex (codes+PQ) */
