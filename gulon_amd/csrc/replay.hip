@@ -89,10 +89,15 @@ __global__ __launch_bounds__(64) void rp_seg_scan(const uint8_t *__restrict__ co
   const Word *cw = reinterpret_cast<const Word *>(codes);
   const int rb0 = rb_begin + s * rb_per_seg;
   const int rb1 = min(rb_end, rb0 + rb_per_seg);
+  // one wave walks the segment alone: keep the next row block's first code word in flight
+  Word w_first{};
+  if (rb0 < rb1) w_first = cw[((size_t)rb0 * ng) * 64 + lane];
   for (int rb = rb0; rb < rb1; rb++) {
     float acc = 0.f;
+    Word w0 = w_first;
+    if (rb + 1 < rb1) w_first = cw[((size_t)(rb + 1) * ng) * 64 + lane];
     for (int g = 0; g < ng; g++) {
-      Word w = cw[((size_t)rb * ng + g) * 64 + lane];
+      Word w = g == 0 ? w0 : cw[((size_t)rb * ng + g) * 64 + lane];
       const float *tj = tab + g * VEC * 256;
 #pragma unroll
       for (int b = 0; b < VEC; b++) acc += tj[b * 256 + rp_byte(w, b)];
@@ -128,95 +133,130 @@ __global__ __launch_bounds__(64) void rp_seg_scan(const uint8_t *__restrict__ co
   }
 }
 
-// exclusive prefix over segments of "the K smallest distances so far"; one wave per query
+// exclusive prefix over segments of "the K smallest distances so far"; one wave per query.
+// Segment s+1's list is prefetched (one coalesced load, lane e = entry e) while s is merged.
 __global__ __launch_bounds__(64) void rp_prefix(const float *__restrict__ segtop, const int *__restrict__ segcnt,
                                                 const int *__restrict__ count, int maxf, int nseg, int K,
                                                 float *__restrict__ prefix, int *__restrict__ precnt) {
   const int lane = threadIdx.x;
   const int nf = min(*count, maxf);
   for (int f = blockIdx.x; f < nf; f += gridDim.x) {
-  WaveList wl;
-  wl.init();
-  int cnt = 0;
-  for (int s = 0; s < nseg; s++) {
-    const size_t fs = (size_t)f * nseg + s;
-    if (lane < K) prefix[fs * K + lane] = wl.v;
-    if (lane == 0) precnt[fs] = cnt;
-    const int sc = segcnt[fs];
-    for (int e = 0; e < sc; e++) {
-      float cv = segtop[fs * K + e];
-      if (cnt < K || cv < wl.tau) {
-        wl.insert(cv, s * 64 + e, K, lane);
-        if (cnt < K) cnt++;
-      } else {
-        break;   // segtop is ascending: nothing smaller follows
+    WaveList wl;
+    wl.init();
+    int cnt = 0;
+    const size_t f0 = (size_t)f * nseg;
+    float nxt_v = lane < K ? segtop[f0 * K + lane] : INFINITY;
+    int nxt_c = segcnt[f0];
+    for (int s = 0; s < nseg; s++) {
+      const size_t fs = f0 + s;
+      const float cur_v = nxt_v;
+      const int sc = nxt_c;
+      if (s + 1 < nseg) {
+        nxt_v = lane < K ? segtop[(fs + 1) * K + lane] : INFINITY;
+        nxt_c = segcnt[fs + 1];
+      }
+      if (lane < K) prefix[fs * K + lane] = wl.v;
+      if (lane == 0) precnt[fs] = cnt;
+      for (int e = 0; e < sc; e++) {
+        float cv = readlane_f(cur_v, e);
+        if (cnt < K || cv < wl.tau) {
+          wl.insert(cv, s * 64 + e, K, lane);
+          if (cnt < K) cnt++;
+        } else {
+          break;   // segtop is ascending: nothing smaller follows
+        }
       }
     }
-  }
   }
 }
 
-// literal TopKHeap (TopKHeap.scala) over the events, then Result.fromHeap (Index.scala:83-94)
-__global__ void rp_heap(const float *__restrict__ evv, const int *__restrict__ evi, const int *__restrict__ evcnt,
-                        const int *__restrict__ overflow, const int *__restrict__ list,
-                        const int *__restrict__ count, int maxf, int nseg, int evcap, int K, int *__restrict__ out_idx,
-                        float *__restrict__ out_dist, int *__restrict__ out_count, int *__restrict__ out_flags) {
+// literal TopKHeap (TopKHeap.scala) over the events, then Result.fromHeap (Index.scala:83-94).
+// One wave per flagged query: the lanes first pack the per-segment event lists into one
+// contiguous LDS array (wave prefix sum over the segment counts), then lane 0 runs the heap.
+constexpr int RP_LDS_EVENTS = 4096;
+__global__ __launch_bounds__(64) void rp_heap(const float *__restrict__ evv, const int *__restrict__ evi,
+                                              const int *__restrict__ evcnt, const int *__restrict__ overflow,
+                                              const int *__restrict__ list, const int *__restrict__ count, int maxf,
+                                              int nseg, int evcap, int K, int *__restrict__ out_idx,
+                                              float *__restrict__ out_dist, int *__restrict__ out_count,
+                                              int *__restrict__ out_flags) {
+  __shared__ float sv[RP_LDS_EVENTS];
+  __shared__ int si[RP_LDS_EVENTS];
+  __shared__ int hk[GULON_MAX_K + 1];
+  __shared__ float hv[GULON_MAX_K + 1];
+  const int lane = threadIdx.x;
   const int nf = min(*count, maxf);
-  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
-  if (overflow[f]) continue;   // keeps the (distance, row id) result and its tie flags
-  int keys[GULON_MAX_K];
-  float vals[GULON_MAX_K];
-  int size = 0;
-  auto swp = [&](int a, int b) {
-    int tk = keys[a]; float tv = vals[a];
-    keys[a] = keys[b]; vals[a] = vals[b];
-    keys[b] = tk; vals[b] = tv;
-  };
-  auto down = [&](int i) {                                  // percolateDown, TopKHeap.scala:30-42
-    for (;;) {
-      int top = i, lc = 2 * i + 1, rc = 2 * i + 2;
-      if (lc < size && vals[top] < vals[lc]) top = lc;
-      if (rc < size && vals[top] < vals[rc]) top = rc;
-      if (top == i) break;
-      swp(i, top);
-      i = top;
-    }
-  };
-  auto del = [&]() {                                        // delete, TopKHeap.scala:57-67
-    size -= 1;
-    keys[0] = keys[size];
-    vals[0] = vals[size];
-    down(0);
-  };
-  for (int s = 0; s < nseg; s++) {
-    const size_t fs = (size_t)f * nseg + s;
-    const int ne = evcnt[fs];
-    for (int e = 0; e < ne; e++) {
-      const float v = evv[fs * evcap + e];
-      const int kk = evi[fs * evcap + e];
-      if (size == K && vals[0] > v) del();                  // update, TopKHeap.scala:69-79
-      if (size < K) {
-        keys[size] = kk;
-        vals[size] = v;
-        int i = size;
-        while (i > 0) {                                     // percolateUp, TopKHeap.scala:21-28
-          int p = (i - 1) / 2;
-          if (vals[i] > vals[p]) { swp(i, p); i = p; } else break;
-        }
-        size += 1;
+  for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+    __syncthreads();
+    if (overflow[f]) continue;   // keeps the (distance, row id) result and its tie flags
+    // pack events: segment order = row order
+    int total = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+      const int s = s0 + lane;
+      const size_t fs = (size_t)f * nseg + s;
+      const int c = s < nseg ? evcnt[fs] : 0;
+      int inc = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
       }
+      const int base = total + inc - c;
+      for (int e = 0; e < c; e++) {
+        if (base + e < RP_LDS_EVENTS) { sv[base + e] = evv[fs * evcap + e]; si[base + e] = evi[fs * evcap + e]; }
+      }
+      total += __shfl(inc, 63);
     }
-  }
-  const int q = list[f];
-  const int live = size;
-  for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
-    out_idx[(size_t)q * K + i] = keys[0];
-    out_dist[(size_t)q * K + i] = vals[0];
-    del();
-  }
-  for (int i = live; i < K; i++) { out_idx[(size_t)q * K + i] = -1; out_dist[(size_t)q * K + i] = INFINITY; }
-  if (out_count) out_count[q] = live;
-  out_flags[q] |= GULON_FLAG_EXACT_REPLAY;
+    __syncthreads();
+    if (total > RP_LDS_EVENTS) continue;   // too many events for the LDS staging: leave the flagged result
+    if (lane == 0) {
+      int size = 0;
+      auto swp = [&](int a, int b) {
+        int tk = hk[a]; float tv = hv[a];
+        hk[a] = hk[b]; hv[a] = hv[b];
+        hk[b] = tk; hv[b] = tv;
+      };
+      auto down = [&](int i) {                                  // percolateDown, TopKHeap.scala:30-42
+        for (;;) {
+          int top = i, lc = 2 * i + 1, rc = 2 * i + 2;
+          if (lc < size && hv[top] < hv[lc]) top = lc;
+          if (rc < size && hv[top] < hv[rc]) top = rc;
+          if (top == i) break;
+          swp(i, top);
+          i = top;
+        }
+      };
+      auto del = [&]() {                                        // delete, TopKHeap.scala:57-67
+        size -= 1;
+        hk[0] = hk[size];
+        hv[0] = hv[size];
+        down(0);
+      };
+      for (int e = 0; e < total; e++) {
+        const float v = sv[e];
+        const int kk = si[e];
+        if (size == K && hv[0] > v) del();                      // update, TopKHeap.scala:69-79
+        if (size < K) {
+          hk[size] = kk;
+          hv[size] = v;
+          int i = size;
+          while (i > 0) {                                       // percolateUp, TopKHeap.scala:21-28
+            int p = (i - 1) / 2;
+            if (hv[i] > hv[p]) { swp(i, p); i = p; } else break;
+          }
+          size += 1;
+        }
+      }
+      const int q = list[f];
+      const int live = size;
+      for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
+        out_idx[(size_t)q * K + i] = hk[0];
+        out_dist[(size_t)q * K + i] = hv[0];
+        del();
+      }
+      for (int i = live; i < K; i++) { out_idx[(size_t)q * K + i] = -1; out_dist[(size_t)q * K + i] = INFINITY; }
+      if (out_count) out_count[q] = live;
+      out_flags[q] |= GULON_FLAG_EXACT_REPLAY;
+    }
   }
 }
 
@@ -243,7 +283,7 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
                      ix->rp_count.p);
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)maxf * ix->d, 256)), dim3(256), 0, st, dQ, ix->d,
                      maxf, ix->rp_list.p, ix->rp_count.p, ix->rp_q.p);
-  launch_build_tables(1, ix, ix->rp_q.p, maxf, maxf, ix->rp_tables.p, st);
+  launch_build_tables(1, ix, ix->rp_q.p, maxf, maxf, ix->rp_tables.p, st, ix->rp_count.p);
   const size_t lds = (size_t)ix->m_pad * 256 * sizeof(float);
 #define SEG(V, PH)                                                                                                 \
   do {                                                                                                             \
@@ -260,7 +300,7 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
                      maxf, nseg, K, ix->rp_prefix.p, ix->rp_precnt.p);
   if (ix->vec == 16) SEG(16, 1); else SEG(4, 1);
 #undef SEG
-  hipLaunchKernelGGL(rp_heap, dim3(std::min(ceil_div(maxf, 64), 4)), dim3(64), 0, st, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p,
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(maxf, 64)), dim3(64), 0, st, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p,
                      ix->rp_overflow.p, ix->rp_list.p, ix->rp_count.p, maxf, nseg, evcap, K, d_oi, d_od, d_oc, d_of);
   HIP_CHECK(hipGetLastError());
 }

@@ -67,9 +67,11 @@ __global__ void narrow_codes(const uint16_t *__restrict__ in, long long total, u
 template <bool INTERLEAVED, int W>
 __global__ void build_tables(const float *__restrict__ cents, const int *__restrict__ from,
                              const int *__restrict__ sdim, int d, int m, int k, int m_pad,
-                             const float *__restrict__ Q, int B, float *__restrict__ T) {
+                             const float *__restrict__ Q, int B, float *__restrict__ T,
+                             const int *__restrict__ live_queries) {
   // one thread per (query group of W, quantizer, centroid)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (live_queries) B = min(B, *live_queries);   // device-side query count (tie replay: usually 0)
   int nqg = (B + W - 1) / W;
   long long total = (long long)nqg * m_pad * 256;
   if (t >= total) return;
@@ -136,8 +138,11 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
     int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
-    int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi) {
+    int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi,
+    unsigned long long *__restrict__ dbg) {
   constexpr int QT = W * NSUB;
+  // optional timeline (GULON_SCAN_TIMELINE=1): 4 stamps per workgroup, 100 MHz wall clock
+  if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = wall_clock64();
   constexpr int NW = THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
   using TV = typename TabVec<W>::type;
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   }
   __syncthreads();
 
+  if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 1] = wall_clock64();
   WaveList wl[QT];
   int cnt[QT];
 #pragma unroll
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
 
   // merge the NW per-wave lists of every query through LDS (tables are dead now)
   __syncthreads();
+  if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = wall_clock64();
   float *sv = reinterpret_cast<float *>(lds_raw);
   int *si = reinterpret_cast<int *>(sv + QT * NW * 64);
 #pragma unroll
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
       __hip_atomic_fetch_min(&gtau[tile * QT + q], __float_as_uint(out.tau), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------
@@ -455,12 +463,13 @@ void launch_peel_finalize(const float *pv, const int *pi, int B, int cap, int K,
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st) {
+void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
+                         const int *live_queries) {
   long long total = (long long)(Bpad / W) * ix->m_pad * 256;
   if (total <= 0) return;
 #define BT(WW)                                                                                             \
   hipLaunchKernelGGL((build_tables<true, WW>), dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p,   \
-                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, tables)
+                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, tables, live_queries)
   if (W == 4) BT(4); else if (W == 2) BT(2); else BT(1);
 #undef BT
   HIP_CHECK(hipGetLastError());
@@ -506,14 +515,39 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
   lds_bytes += 64;
   int prune_from = tuning().prune_from >= 0 ? tuning().prune_from : ix->m_pad / 2;
   if (prune_from < 4) prune_from = 4;
+  unsigned long long *dbg = nullptr;
+  if (getenv("GULON_SCAN_TIMELINE")) {
+    ix->dbg.ensure((size_t)ntiles * nchunks * 4);
+    dbg = ix->dbg.p;
+  }
   auto kern = scan_kernel<W, NSUB, VEC, SCAN_THREADS, PRUNE>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, rb_end,
                      rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
-                     lbi);
+                     lbi, dbg);
   HIP_CHECK(hipGetLastError());
+  if (dbg) {   // debugging aid: synchronous dump of the per-workgroup timeline
+    HIP_CHECK(hipStreamSynchronize(st));
+    const size_t nb = (size_t)ntiles * nchunks;
+    std::vector<unsigned long long> h(nb * 4);
+    HIP_CHECK(hipMemcpy(h.data(), dbg, sizeof(unsigned long long) * nb * 4, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double stage = 0, loop = 0, merge = 0;
+    for (size_t b = 0; b < nb; b++) {
+      t0 = std::min(t0, h[b * 4]); t1 = std::max(t1, h[b * 4 + 3]);
+      stage += (double)(h[b * 4 + 1] - h[b * 4]); loop += (double)(h[b * 4 + 2] - h[b * 4 + 1]);
+      merge += (double)(h[b * 4 + 3] - h[b * 4 + 2]);
+    }
+    std::vector<double> ends;
+    for (size_t b = 0; b < nb; b++) ends.push_back((double)(h[b * 4 + 3] - t0) / 100.0);
+    std::sort(ends.begin(), ends.end());
+    fprintf(stderr, "[scan timeline] %zu workgroups, kernel span %.1f us; per workgroup: stage %.1f us, loop %.1f us, "
+            "merge %.1f us; last-finish quantiles 50%%=%.0f 90%%=%.0f 99%%=%.0f 100%%=%.0f us\n", nb,
+            (double)(t1 - t0) / 100.0, stage / nb / 100.0, loop / nb / 100.0, merge / nb / 100.0,
+            ends[nb / 2], ends[nb * 9 / 10], ends[nb * 99 / 100], ends[nb - 1]);
+  }
 }
 
 template <int W, int NSUB, int VEC>
@@ -847,7 +881,7 @@ GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, 
     dc.upload(cents, (size_t)k * d); dq.upload(queries, (size_t)b * d);
     long long total = (long long)((b + 3) / 4) * m * 256;
     hipLaunchKernelGGL((build_tables<false, 4>), dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
-                       m, dq.p, b, dt.p);
+                       m, dq.p, b, dt.p, (const int *)nullptr);
     HIP_CHECK(hipGetLastError());
     dt.download(t_out, (size_t)b * m * k);
     HIP_CHECK(hipDeviceSynchronize());

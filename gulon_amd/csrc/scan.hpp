@@ -38,6 +38,7 @@ struct gulon_index {
   DevBuf<int> stage_oi, stage_oc, stage_of;
   DevBuf<float> stage_od;
   DevBuf<int> flags_scratch;
+  DevBuf<unsigned long long> dbg;   // GULON_SCAN_TIMELINE stamps
   // large-K peeling rounds
   DevBuf<float> peel_v, peel_tv, peel_lbv;
   DevBuf<int> peel_i, peel_ti, peel_lbi;
@@ -56,7 +57,8 @@ struct gulon_index {
 
 namespace gulon {
 // Index.prepareQuery tables, W queries interleaved (scan.hip)
-void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st);
+void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
+                         const int *live_queries = nullptr);
 // For every query flagged with an exact distance tie, recompute the result with the
 // reference's TopKHeap semantics (insertion history in row order) -- replay.hip
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,

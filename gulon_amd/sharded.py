@@ -3,7 +3,7 @@
 The code matrix is split into `world` contiguous row ranges -- exactly the
 from/until contract of PQIndex.batchQuery (Index.scala:417-419).  Every rank
 builds the same distance tables, scans its own rows, and the per-shard partial
-top-(K+1) lists are exchanged with ONE all-gather per array (RCCL over xGMI when
+top-(K+1) lists are exchanged with ONE all-gather (RCCL over xGMI when
 the process group is "nccl"); each rank then merges the `world` lists with
 TopKHeap.merge semantics (TopKHeap.scala:44-53, used the same way by
 Index.scala:279) under the deterministic (distance, row id) order, so the
@@ -64,9 +64,16 @@ class HipEngine:
         N.check(N.lib().gulon_index_scan_partial_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, pv.data_ptr(),
                                                      pi.data_ptr(), self._stream()))
 
-    def merge(self, all_v, all_i, lists, b, k, oi, od, oc, of):
-        N.check(N.lib().gulon_topk_merge_dev(all_v.data_ptr(), all_i.data_ptr(), lists, 0, b, k, oi.data_ptr(),
-                                             od.data_ptr(), oc.data_ptr(), of.data_ptr(), self._stream()))
+    def merge(self, packed, lists, b, k, oi, od, oc, of):
+        """packed: [lists][2][B][K+1] int32 words (distance bits, then row ids) as gathered."""
+        base = packed.data_ptr()
+        N.check(N.lib().gulon_topk_merge_dev(base, base + 4 * b * (k + 1), lists, 2 * b * (k + 1), b, k,
+                                             oi.data_ptr(), od.data_ptr(), oc.data_ptr(), of.data_ptr(),
+                                             self._stream()))
+
+    def views(self, pk, b):
+        """(float32 view of the distance half, int32 row-id half) of a [2*B][K+1] int32 buffer."""
+        return pk[:b].view(self.torch.float32), pk[b:]
 
 
 class ShardedIndex:
@@ -88,9 +95,12 @@ class ShardedIndex:
             e = self.engine
             self._bufs[key] = dict(
                 oi=e.alloc((b, k), "i32"), od=e.alloc((b, k), "f32"), oc=e.alloc((b,), "i32"),
-                of=e.alloc((b,), "i32"), pv=e.alloc((b, k + 1), "f32"), pi=e.alloc((b, k + 1), "i32"),
-                # gathered lists, rank-major: [world*B][K+1] == [world][B][K+1]
-                av=e.alloc((self.world * b, k + 1), "f32"), ai=e.alloc((self.world * b, k + 1), "i32"))
+                of=e.alloc((b,), "i32"),
+                # this rank's partial list, one buffer so that ONE all-gather moves it:
+                # rows [0, B) = distance bits, rows [B, 2B) = row ids
+                pk=e.alloc((2 * b, k + 1), "i32"),
+                # gathered, rank-major: [world][2][B][K+1]
+                apk=e.alloc((self.world * 2 * b, k + 1), "i32"))
         return self._bufs[key]
 
     def batch_query_dev(self, q, b, k):
@@ -99,19 +109,16 @@ class ShardedIndex:
         if self.world == 1:
             self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
         else:
-            self.engine.scan_partial(q, b, k, u["pv"], u["pi"])
+            pv, pi = self.engine.views(u["pk"], b)
+            self.engine.scan_partial(q, b, k, pv, pi)
             if self.host_staged:
                 # rehearsal path (gloo has no device collectives): same layout, staged through the host
-                hv, hi = u["pv"].cpu(), u["pi"].cpu()
-                gv, gi = u["av"].cpu(), u["ai"].cpu()
-                self.dist.all_gather_into_tensor(gv, hv)
-                self.dist.all_gather_into_tensor(gi, hi)
-                u["av"].copy_(gv)
-                u["ai"].copy_(gi)
+                hp, gp = u["pk"].cpu(), u["apk"].cpu()
+                self.dist.all_gather_into_tensor(gp, hp)
+                u["apk"].copy_(gp)
             else:
-                self.dist.all_gather_into_tensor(u["av"], u["pv"])
-                self.dist.all_gather_into_tensor(u["ai"], u["pi"])
-            self.engine.merge(u["av"], u["ai"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
+                self.dist.all_gather_into_tensor(u["apk"], u["pk"])
+            self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
         return u["oi"], u["od"], u["oc"], u["of"]
 
     def batch_query(self, k, queries):

@@ -34,9 +34,13 @@ class OracleEngine:
         pv.copy_(torch.from_numpy(v))
         pi.copy_(torch.from_numpy(i))
 
-    def merge(self, all_v, all_i, lists, b, k, oi, od, oc, of):
-        av = all_v.numpy().reshape(lists, b, k + 1)
-        ai = all_i.numpy().reshape(lists, b, k + 1)
+    def views(self, pk, b):
+        return pk[:b].view(torch.float32), pk[b:]
+
+    def merge(self, packed, lists, b, k, oi, od, oc, of):
+        w = packed.numpy().reshape(lists, 2, b, k + 1)
+        av = np.ascontiguousarray(w[:, 0]).view(np.float32)
+        ai = np.ascontiguousarray(w[:, 1])
         for r in range(b):
             cand = sorted((float(av[l, r, e]), int(ai[l, r, e])) for l in range(lists) for e in range(k + 1)
                           if ai[l, r, e] != INT_MAX)
