@@ -5,6 +5,8 @@
 // java.util.Random).  v_mfma_f32_32x32x2_f32 computes the same quantity as an fma chain
 // (one rounding per product-add), so its value d' differs from d by at most
 //     E = (2s+1) * 2^-24 * (|c|^2 + 2 |x||c|) * (1 + o(1))
+// (the epilogue additionally perturbs d' by <= 31 ulp to carry the centroid index; that is
+// added to the band)
 // (Higham's gamma bounds for both chains).  The filter replays the reference's scan over
 // c = 0..k-1 on d':  if every comparison against the running minimum is decided by more
 // than 2E, the reference's scan takes exactly the same branches, draws no random bit, and
@@ -65,21 +67,37 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
                                                    unsigned *__restrict__ flag_count) {
   extern __shared__ float sm[];
   float *sA = sm;                       // nkb*T*64
-  float *sOff = sm + (size_t)nkb * T * 64;  // nkb*32
+  float *sOff = sm + (size_t)nkb * T * 64;  // 2 copies of nkb*32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < nkb * T * 64; e += 256) sA[e] = apack[e];
-  for (int e = tid; e < nkb * 32; e += 256) sOff[e] = offp[e];
+  for (int e = tid; e < nkb * 32; e += 256) { sOff[e] = offp[e]; sOff[nkb * 32 + e] = offp[e]; }
   __syncthreads();
   const float cmax2 = __uint_as_float(*cmax2_bits);
   const int half = lane >> 5;
 
-  for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += (long long)gridDim.x * 4) {
-    const float *px = xq + (size_t)(2 * pp) * T * 64 + lane;
-    float bx[T], by[T];
+  // B operands of the NEXT tile pair are loaded while the current one is in the matrix pipe
+  const long long pstride = (long long)gridDim.x * 4;
+  float nbx[T], nby[T];
+  {
+    const long long pp0 = (long long)blockIdx.x * 4 + wave;
+    const float *px = xq + (size_t)(2 * min(pp0, npairs - 1)) * T * 64 + lane;
 #pragma unroll
     for (int t = 0; t < T; t++) {
-      bx[t] = px[(size_t)t * 64];
-      by[t] = px[(size_t)(T + t) * 64];
+      nbx[t] = px[(size_t)t * 64];
+      nby[t] = px[(size_t)(T + t) * 64];
+    }
+  }
+  for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += pstride) {
+    float bx[T], by[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) { bx[t] = nbx[t]; by[t] = nby[t]; }
+    {
+      const float *px = xq + (size_t)(2 * min(pp + pstride, npairs - 1)) * T * 64 + lane;   // clamped: always valid
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        nbx[t] = px[(size_t)t * 64];
+        nby[t] = px[(size_t)(T + t) * 64];
+      }
     }
     // |x|^2 of the row this lane will own after the swap
     float nx = 0.f, ny = 0.f;
@@ -92,21 +110,23 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
     // 2E band (see file header); non-finite inputs make it NaN => row flagged below
     const float e2 = errk * (cmax2 + 2.0f * __fsqrt_rn(nx * cmax2)) + 1e-30f;
 
-    float pmin = FLT_MAX;
+    float pmin = FLT_MAX;      // running minimum key
+    float mband = INFINITY;    // smallest |key - running minimum| seen by this row's scan
     int best = -1;
-    unsigned long long amb = 0ull;
 
     // one centroid block = 2*T MFMAs (tiles X and Y), C-init = offsets
     auto mfma_block = [&](int kb, f32x16 &ax, f32x16 &ay) {
-      f32x16 cinit;
+      // C-init = offsets.  The two accumulator tiles are initialised by two separate LDS reads
+      // (sOff is stored twice) instead of 32 register copies of one read.
       const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 4 * half);
+      const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 4 * half);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         float4 o = so[2 * g];   // centroids 8g + 4*half + (0..3)
-        cinit[4 * g + 0] = o.x; cinit[4 * g + 1] = o.y; cinit[4 * g + 2] = o.z; cinit[4 * g + 3] = o.w;
+        ax[4 * g + 0] = o.x; ax[4 * g + 1] = o.y; ax[4 * g + 2] = o.z; ax[4 * g + 3] = o.w;
+        float4 o2 = so2[2 * g];
+        ay[4 * g + 0] = o2.x; ay[4 * g + 1] = o2.y; ay[4 * g + 2] = o2.z; ay[4 * g + 3] = o2.w;
       }
-      ax = cinit;
-      ay = cinit;
       const float *pa = sA + (size_t)kb * T * 64 + lane;
 #pragma unroll
       for (int t = 0; t < T; t++) {
@@ -116,12 +136,8 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
       }
     };
 
-    f32x16 ax, ay;
-    mfma_block(0, ax, ay);
-    for (int kb = 0; kb < nkb; kb++) {
-      // software pipeline: the matrix pipe works on block kb+1 while the VALU scans block kb
-      f32x16 nax = ax, nay = ay;
-      if (kb + 1 < nkb) mfma_block(kb + 1, nax, nay);
+    // scan epilogue of one centroid block held in (ax, ay)
+    auto scan_block = [&](int kb, f32x16 &ax, f32x16 &ay) {
       // lanes 0-31 end up with tile X's row (lane), lanes 32-63 with tile Y's row (lane-32):
       // ax[r] = centroids 8(r>>2) + (r&3), ay[r] = centroids 8(r>>2) + 4 + (r&3) of this block
 #pragma unroll
@@ -130,35 +146,46 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
         ax[r] = __uint_as_float(sw[0]);
         ay[r] = __uint_as_float(sw[1]);
       }
-      // The reference's scan over c on d' (ascending centroid index), arranged so that the
-      // only serial dependency is ONE v_min per value (the running minimum); the band test
-      // and the winner search hang off it in parallel:
-      //   q[j]   = min(q[j-1], v[j])                      running minimum (q[-1] = pmin)
-      //   amb   |= |v[j] - q[j-1]| <= 2E                  comparison too close to call
-      //   bl     = first j with v[j] == q[31]             winner inside the block, if any
-      float vv[32], q[32];
-#pragma unroll
-      for (int j = 0; j < 32; j++) vv[j] = ((j >> 2) & 1) ? ay[4 * (j >> 3) + (j & 3)] : ax[4 * (j >> 3) + (j & 3)];
+      // The reference's scan over c on d' (ascending centroid index), in 3.5 VALU ops per
+      // distance.  The position j inside the block replaces the 5 low mantissa bits of d'
+      // ("key"), so ONE running float minimum carries both the value and the winner; the
+      // band test accumulates  min |key_j - running_min_before_j|  with a 3-input min and is
+      // compared once per row.  The <= 31 ulp key perturbation is part of the band (errk).
+      unsigned key[32];
 #pragma unroll
       for (int j = 0; j < 32; j++) {
-        const float prev = j == 0 ? pmin : q[j - 1];
-        // plain v_min_f32: the intrinsic form would add a canonicalising v_max per value
-        asm("v_min_f32 %0, %1, %2" : "=v"(q[j]) : "v"(prev), "v"(vv[j]));
-        amb |= __ballot(__builtin_fabsf(vv[j] - prev) <= e2);
+        const float v = ((j >> 2) & 1) ? ay[4 * (j >> 3) + (j & 3)] : ax[4 * (j >> 3) + (j & 3)];
+        key[j] = (__float_as_uint(v) & ~31u) | (unsigned)j;
       }
-      const float pafter = q[31];
-      int bl = -1;
+      const float qbefore = pmin;
 #pragma unroll
-      for (int j = 31; j >= 0; j--) bl = vv[j] == pafter ? j : bl;
-      best = pafter < pmin ? kb * 32 + bl : best;
-      pmin = pafter;
-      ax = nax;
-      ay = nay;
+      for (int j = 0; j < 32; j += 2) {
+        const float k0 = __uint_as_float(key[j]), k1 = __uint_as_float(key[j + 1]);
+        float q0, q1;
+        // plain v_min_f32 / v_min3_f32: the intrinsic forms add a canonicalising v_max per value
+        asm("v_min_f32 %0, %1, %2" : "=v"(q0) : "v"(pmin), "v"(k0));
+        asm("v_min_f32 %0, %1, %2" : "=v"(q1) : "v"(q0), "v"(k1));
+        const float d0 = k0 - pmin, d1 = k1 - q0;
+        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
+        pmin = q1;
+      }
+      if (__float_as_uint(pmin) != __float_as_uint(qbefore)) best = kb * 32 + (int)(__float_as_uint(pmin) & 31u);
+    };
+
+    // software pipeline without register copies: two accumulator sets alternate, the matrix
+    // pipe works on block kb+1 while the VALU scans block kb
+    f32x16 ax, ay, bx2, by2;
+    mfma_block(0, ax, ay);
+    for (int kb = 0; kb < nkb; kb += 2) {
+      if (kb + 1 < nkb) mfma_block(kb + 1, bx2, by2);
+      scan_block(kb, ax, ay);
+      if (kb + 2 < nkb) mfma_block(kb + 2, ax, ay);
+      if (kb + 1 < nkb) scan_block(kb + 1, bx2, by2);
     }
 
     const long long row = pp * 64 + lane;
     const bool in_range = row < n;
-    const bool my_amb = ((amb >> lane) & 1ull) != 0ull;
+    const bool my_amb = !(mband > e2);   // also true when mband is NaN
     const bool flagged = in_range && (my_amb || best < 0 || !(e2 < INFINITY) || !(fabsf(pmin) < INFINITY));
     if (in_range && !flagged) assign[row] = best;
     const unsigned long long fm = __ballot(flagged);
@@ -175,7 +202,7 @@ bool mfma_assign_supported(int s, int k) {
   if (getenv("GULON_KMEANS_NO_MFMA")) return false;
   int T = (s + 1) / 2;
   int nkb = (k + 31) / 32;
-  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 32) * sizeof(float);
+  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
   return s >= 1 && T <= 8 && lds <= 60 * 1024;
 }
 
@@ -208,9 +235,10 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
   hipLaunchKernelGGL(pack_centroids_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, st, dC, ws.off.p, k, s, T,
                      nkb, ws.apack.p, ws.offp.p, ws.cmax2.p);
   const long long npairs = ((long long)n + 63) / 64;
-  // 2E = 2.1 * (2s+4) * 2^-24 * (|c|max^2 + 2|x||c|max): margins cover sqrt/norm rounding
-  const float errk = 2.1f * (float)(2 * s + 4) * 5.9604645e-8f;
-  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 32) * sizeof(float);
+  // band = 2E + key perturbation: 2.1 * (2s+4) * 2^-24 * S  +  2 * 31 ulp * S,  S = |c|max^2 + 2|x||c|max
+  // (margins cover sqrt/norm rounding; the second term is the index embedded in 5 mantissa bits)
+  const float errk = 2.1f * (float)(2 * s + 4) * 5.9604645e-8f + 2.1f * 31.0f * 1.1920929e-7f;
+  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
   int grid = (int)std::min<long long>((npairs + 3) / 4, 256 * 8);
   if (grid < 1) grid = 1;
 #define AM(TT)                                                                                                   \
