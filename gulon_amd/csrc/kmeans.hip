@@ -191,9 +191,12 @@ __global__ __launch_bounds__(256) void assign_resolve(const float *__restrict__ 
                                                       const unsigned *__restrict__ ties,
                                                       const unsigned *__restrict__ local,
                                                       const unsigned long long *__restrict__ block_off, int seg_len,
-                                                      int bps, int *__restrict__ assign) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || ties[i] == 0) return;
+                                                      int bps, const int *__restrict__ rows, int nrows,
+                                                      int *__restrict__ assign) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nrows) return;
+  int i = rows ? rows[t] : t;          // only the flagged rows can draw when the MFMA filter ran
+  if (ties[i] == 0) return;
   int seg = i / seg_len;
   int blk = (i - seg * seg_len) / 1024;
   unsigned long long pos = block_off[(size_t)seg * bps + blk] + local[i];
@@ -494,8 +497,11 @@ static void launch_tie_replay(AssignJob &j) {
   hipLaunchKernelGGL(tie_block_sums, dim3(bps, nseg), dim3(1024), 0, j.st, ws.ties.p, n, seg_len, bps, ws.local.p,
                      ws.block_tot.p);
   hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, j.st, ws.block_tot.p, bps, ws.block_off.p);
-  hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(n, 256)), dim3(256), 0, j.st, j.dX, n, j.ld, j.from, j.s,
-                     ws.cpad.p, smax, ws.off.p, j.k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, j.d_assign);
+  const int *rows = j.filtered ? j.rows : nullptr;
+  const int nrows = j.filtered ? j.nrows : n;
+  hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(nrows, 256)), dim3(256), 0, j.st, j.dX, n, j.ld, j.from, j.s,
+                     ws.cpad.p, smax, ws.off.p, j.k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, rows, nrows,
+                     j.d_assign);
   HIP_CHECK(hipGetLastError());
 }
 
