@@ -154,6 +154,55 @@ def test_large_k_peeling(oracle, g, n, d, m, k, B, K, frm, until):
     ix.close()
 
 
+def test_degenerate_shapes(oracle, g):
+    """Empty batch, k_nn = 0, empty index, one row: same (empty) answers as the reference."""
+    cents, idx, pq, enc = _make(oracle, g, 300, 16, 4, 16, seed=4)
+    ix = g.PQIndex(pq, enc)
+    assert ix.batch_query(5, np.zeros((0, 16), np.float32)) == []
+    r = ix.batch_query(0, np.zeros((2, 16), np.float32))
+    assert [len(x) for x in r] == [0, 0]
+    ix.close()
+    coder = pq.coder_factory(0)
+    empty = g.PQIndex(pq, g.EncodedMatrix(coder, [np.zeros(0, np.uint8)] * 4))
+    r = empty.batch_query(3, np.zeros((2, 16), np.float32))
+    assert [len(x) for x in r] == [0, 0]
+    empty.close()
+    coder1 = pq.coder_factory(1)
+    one = g.PQIndex(pq, g.EncodedMatrix(coder1, [coder1.build_code(idx[j, :1]) for j in range(4)]))
+    Q = np.random.default_rng(0).standard_normal((3, 16)).astype(np.float32)
+    res = one.batch_query(4, Q)
+    oi, od, oc = oracle.pq_batch_query(np.ascontiguousarray(idx[:, :1]), 16, 16, cents, Q, 4)
+    for q, r in enumerate(res):
+        assert r.rows.tolist() == oi[q, :oc[q]].tolist() == [0]
+        assert np.array_equal(bits(r.distances), bits(od[q, :1]))
+    one.close()
+
+
+def test_concurrent_queries_on_one_index(oracle, g):
+    """The recall harness queries one index from many threads (Tests.scala:109-122)."""
+    import threading
+    n, d, m, k = 20000, 32, 8, 256
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=21)
+    ix = g.PQIndex(pq, enc)
+    Q = np.random.default_rng(2).standard_normal((16, d)).astype(np.float32)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, 10)
+    errs = []
+
+    def work(q):
+        try:
+            for _ in range(5):
+                r = ix.query(10, Q[q])
+                assert r.rows.tolist() == oi[q].tolist()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(q,)) for q in range(16)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    ix.close()
+
+
 def test_requirements_raise(oracle, g):
     cents, idx, pq, enc = _make(oracle, g, 1000, 16, 4, 16, seed=2)
     ix = g.PQIndex(pq, enc)
