@@ -49,7 +49,7 @@ def main():
     import gulon_amd as g
     from gulon_amd import native as N
     from gulon_amd.recall import recall_at_k, sample_rows
-    from gulon_amd.sharded import HipEngine, ShardedIndex, local_shard, shard_bounds
+    from gulon_amd.sharded import HipEngine, ShardedIndex, build_sharded, local_shard, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -77,14 +77,22 @@ def main():
     t0 = time.perf_counter()
     dm = g.DeviceMatrix.synthetic(n, d, args.data_kind, 1234, 1000)
     t1 = time.perf_counter()
-    pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, args.train_iters))
-    t2 = time.perf_counter()
-    enc = pq.encode(dm)
-    t3 = time.perf_counter()
-    lo, hi = shard_bounds(n, world, rank)
+    if world == 1:
+        pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, args.train_iters))
+        t2 = time.perf_counter()
+        enc = pq.encode(dm)
+        t3 = time.perf_counter()
+        lo, hi = shard_bounds(n, world, rank)
+        shard = local_shard(pq, enc, lo, hi)
+    else:
+        # quantizer-partitioned training + encoding, codebooks/codes all-gathered, rows re-sharded
+        enc = None
+        pq, shard, lo, hi = build_sharded(dm, k, m, args.train_iters, rank, world, dist,
+                                          dev if dist.get_backend() == "nccl" else None)
+        t2 = t3 = time.perf_counter()
     nloc = hi - lo
     coder = pq.coder_factory(nloc)
-    engine = HipEngine(pq, local_shard(pq, enc, lo, hi), lo, dev)
+    engine = HipEngine(pq, shard, lo, dev)
     sharded = ShardedIndex(engine, n, rank, world, dist)
     index = engine.index
     build_s = dict(synth=t1 - t0, train=t2 - t1, encode=t3 - t2)
@@ -163,7 +171,7 @@ def main():
             result["recall_sd"] = sd
             result["recall_seconds"] = time.perf_counter() - t
             result["tie_flagged_queries"] = int((res_flg != 0).sum())
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and enc is not None and not args.no_cpu_baseline:
             from oracle import oracle                      # CPU baseline leg only (the checker, timed)
             codes_h = np.stack(enc.encodings) if coder.width == 8 else None
             cents = pq.flat_centroids()

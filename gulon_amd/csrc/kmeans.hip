@@ -873,29 +873,60 @@ GULON_API int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int3
   });
 }
 
+// quantizers [j_begin, j_end) of an m-quantizer ProductQuantizer (all of them: 0, m)
+static void pq_train_range(const gulon_dataset *ds, int m, int k, int max_iterations, int j_begin, int j_end,
+                           float *cents_out, gulon_kmeans_report *reports, int max_reports, int32_t *n_reports) {
+  GULON_REQUIRE(ds != nullptr, "dataset is null");
+  GULON_REQUIRE(m >= 1 && m <= ds->d && k >= 1, "bad quantizer shape m=%d k=%d d=%d", m, k, ds->d);
+  GULON_REQUIRE(0 <= j_begin && j_begin <= j_end && j_end <= m, "bad quantizer range [%d,%d) of %d", j_begin, j_end, m);
+  const int np = j_end - j_begin;
+  if (np == 0) return;
+  std::vector<int> from, until, f(np), sdim(np), seeds(np);
+  subvectors(ds->d, m, from, until);
+  std::vector<float *> outs(np);
+  for (int p = 0; p < np; p++) {
+    const int j = j_begin + p;
+    f[p] = from[j];
+    sdim[p] = until[j] - from[j];
+    seeds[p] = j;                                     // ProductQuantizer.scala:139
+    outs[p] = cents_out + (size_t)k * from[j];
+  }
+  kmeans_train_batch(ds->x.p, ds->n, ds->d, np, f.data(), sdim.data(), seeds.data(), k, max_iterations, outs.data(),
+                     reports, max_reports, n_reports);
+}
+
 GULON_API int32_t gulon_pq_train(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
                                  float *cents_out, gulon_kmeans_report *reports, int32_t max_reports,
                                  int32_t *n_reports) {
-  return guarded([&] {
-    GULON_REQUIRE(ds != nullptr, "dataset is null");
-    GULON_REQUIRE(m >= 1 && m <= ds->d && k >= 1, "bad quantizer shape m=%d k=%d d=%d", m, k, ds->d);
-    std::vector<int> from, until, sdim(m), seeds(m);
-    subvectors(ds->d, m, from, until);
-    std::vector<float *> outs(m);
-    for (int j = 0; j < m; j++) {
-      sdim[j] = until[j] - from[j];
-      seeds[j] = j;                                   // ProductQuantizer.scala:139
-      outs[j] = cents_out + (size_t)k * from[j];
-    }
-    kmeans_train_batch(ds->x.p, ds->n, ds->d, m, from.data(), sdim.data(), seeds.data(), k, max_iterations,
-                       outs.data(), reports, max_reports, n_reports);
-  });
+  return guarded([&] { pq_train_range(ds, m, k, max_iterations, 0, m, cents_out, reports, max_reports, n_reports); });
 }
+
+GULON_API int32_t gulon_pq_train_range(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
+                                       int32_t j_begin, int32_t j_end, float *cents_out,
+                                       gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports) {
+  return guarded(
+      [&] { pq_train_range(ds, m, k, max_iterations, j_begin, j_end, cents_out, reports, max_reports, n_reports); });
+}
+
+static void pq_encode_range(const gulon_dataset *ds, int m, int k, const float *cents, int j_begin, int j_end,
+                            uint8_t *codes_out);
 
 GULON_API int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
                                   uint8_t *codes_out) {
-  return guarded([&] {
+  return guarded([&] { pq_encode_range(ds, m, k, cents, 0, m, codes_out); });
+}
+
+// codes_out: (j_end - j_begin) packed code arrays back to back (quantizer j_begin first)
+GULON_API int32_t gulon_pq_encode_range(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
+                                        int32_t j_begin, int32_t j_end, uint8_t *codes_out) {
+  return guarded([&] { pq_encode_range(ds, m, k, cents, j_begin, j_end, codes_out); });
+}
+
+static void pq_encode_range(const gulon_dataset *ds, int m, int k, const float *cents, int j_begin, int j_end,
+                            uint8_t *codes_out) {
+  {
     GULON_REQUIRE(ds != nullptr, "dataset is null");
+    GULON_REQUIRE(0 <= j_begin && j_begin <= j_end && j_end <= m, "bad quantizer range [%d,%d) of %d", j_begin, j_end, m);
     GULON_REQUIRE(m >= 1 && m <= ds->d && k >= 1, "bad quantizer shape m=%d k=%d d=%d", m, k, ds->d);
     int width = -1;
     GULON_REQUIRE(gulon_coder_width(k, &width) == GULON_OK, "too many clusters: %d", k);
@@ -911,14 +942,14 @@ GULON_API int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k,
     DevBuf<uint8_t> d8(n);
     std::vector<int> h_idx;
     PackedSlice packed;
-    for (int j = 0; j < m; j++) {
+    for (int j = j_begin; j < j_end; j++) {
       const int s = until[j] - from[j];
       dc.upload(cents + (size_t)k * from[j], (size_t)k * s);
       HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)n));
       const bool mf = mfma_assign_supported(s, k);
       if (mf) pack_slice(ds->x.p, n, ds->d, from[j], s, packed, nullptr);
       kmeans_assign_dev(ws, ds->x.p, n, ds->d, from[j], s, dc.p, k, 0, da.p, nullptr, mf ? &packed : nullptr);   // serial assign
-      uint8_t *out = codes_out + (size_t)j * bytes;
+      uint8_t *out = codes_out + (size_t)(j - j_begin) * bytes;
       if (width == 8) {                                                                   // Coder8: idx.toByte
         hipLaunchKernelGGL(narrow_assign_u8, dim3(ceil_div(n, 256)), dim3(256), 0, 0, da.p, (long long)n, d8.p);
         HIP_CHECK(hipGetLastError());
@@ -931,5 +962,5 @@ GULON_API int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k,
         GULON_REQUIRE(gulon_coder_build(width, h_idx.data(), n, out) == GULON_OK, "coder failed");
       }
     }
-  });
+  }
 }

@@ -73,6 +73,8 @@ SIGNATURES = {
                                   C.POINTER(_i32)]),
     "gulon_pq_train": (_i32, [_vp, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32, _vp]),
     "gulon_pq_encode": (_i32, [_vp, _i32, _i32, _f32p, _u8p]),
+    "gulon_pq_train_range": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32, _vp]),
+    "gulon_pq_encode_range": (_i32, [_vp, _i32, _i32, _f32p, _i32, _i32, _u8p]),
     "gulon_prepare_query": (_i32, [_f32p, _i32, _i32, _i32, _f32p, _i32, _f32p]),
     "gulon_index_create": (_i32, [_u8p, _i32, _i32, _i32, _i32, _f32p, _i32, C.POINTER(_vp)]),
     "gulon_index_destroy": (_i32, [_vp]),

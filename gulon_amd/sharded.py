@@ -127,3 +127,63 @@ class ShardedIndex:
         b = q.shape[0]
         oi, od, oc, of = self.batch_query_dev(self.engine.to_device(q), b, k)
         return tuple(t.cpu().numpy() for t in (oi, od, oc, of))
+
+
+# ---------------------------------------------------------------------------------------
+# Build side: the m sub-quantizers are independent k-means problems
+# (ProductQuantizer.scala:130-145), so they are partitioned over the ranks -- no collective
+# inside the training loop, which keeps the order-dependent fp32 running means bit-exact.
+# One all-gather of the codebooks at the end, one all-gather of the per-quantizer code
+# arrays, then every rank keeps its row range.
+# ---------------------------------------------------------------------------------------
+def _all_gather_np(arr, dist, device):
+    """All-gather equally-shaped numpy arrays -> [world, ...] numpy (device tensors under RCCL)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    use_dev = device is not None and dist.get_backend() == "nccl"
+    if use_dev:
+        t = t.to(device)
+    out = torch.empty((dist.get_world_size(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() > 1 else out.view(-1), t)
+    return out.cpu().numpy()
+
+
+def build_sharded(dm, num_clusters, num_quantizers, max_iterations, rank=0, world=1, dist=None, device=None):
+    """ProductQuantizer.apply + encode with the quantizers partitioned over `world` ranks.
+
+    Returns (pq, shard, lo, hi): the full ProductQuantizer (identical on every rank and to the
+    single-process result) and the EncodedMatrix of this rank's row range [lo, hi)."""
+    import ctypes as C
+    from .vectors import subvector_bounds
+    n, d, m, k = dm.rows, dm.cols, num_quantizers, num_clusters
+    fr, un = subvector_bounds(d, m)
+    jlo, jhi = shard_bounds(m, world, rank)
+    cents = np.zeros(k * d, np.float32)
+    N.check(N.lib().gulon_pq_train_range(dm._h, m, k, max_iterations, jlo, jhi, cents, None, 0, None))
+    if world > 1:
+        allc = _all_gather_np(cents, dist, device)                      # [world][k*d]
+        for r in range(world):
+            a, b = shard_bounds(m, world, r)
+            if b > a:
+                cents[k * fr[a]: k * un[b - 1]] = allc[r, k * fr[a]: k * un[b - 1]]
+    pq = ProductQuantizer.from_flat(k, d, m, cents)
+
+    coder = pq.coder_factory(n)
+    bpc = coder.bytes_per_code
+    mmax = max(shard_bounds(m, world, r)[1] - shard_bounds(m, world, r)[0] for r in range(world))
+    local = np.zeros((mmax, max(bpc, 1)), np.uint8)
+    if jhi > jlo and bpc > 0:
+        buf = np.zeros((jhi - jlo) * bpc, np.uint8)
+        N.check(N.lib().gulon_pq_encode_range(dm._h, m, k, cents, jlo, jhi, buf))
+        local[: jhi - jlo, :bpc] = buf.reshape(jhi - jlo, bpc)
+    if world > 1:
+        allcodes = _all_gather_np(local, dist, device)                  # [world][mmax][bpc]
+        encs = []
+        for r in range(world):
+            a, b = shard_bounds(m, world, r)
+            encs.extend(allcodes[r, j, :bpc] for j in range(b - a))
+    else:
+        encs = [local[j, :bpc] for j in range(m)]
+    full = EncodedMatrix(coder, encs)
+    lo, hi = shard_bounds(n, world, rank)
+    return pq, local_shard(pq, full, lo, hi), lo, hi

@@ -137,12 +137,22 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
 int32_t gulon_pq_train(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
                        float *cents_out, gulon_kmeans_report *reports, int32_t max_reports,
                        int32_t *n_reports);
+/* The same for quantizers [j_begin, j_end) only -- the unit of work when the m independent
+ * sub-quantizers are trained on different GPUs (ProductQuantizer.scala:130-145 runs them with
+ * parTraverse).  Only those quantizers' blocks of cents_out are written; reports/n_reports are
+ * indexed from j_begin. */
+int32_t gulon_pq_train_range(const gulon_dataset *ds, int32_t m, int32_t k, int32_t max_iterations,
+                             int32_t j_begin, int32_t j_end, float *cents_out, gulon_kmeans_report *reports,
+                             int32_t max_reports, int32_t *n_reports);
 /* ProductQuantizer.encode (ProductQuantizer.scala:25-35): per quantizer the serial
  * assign, packed by the Coder for k (coderFactory :11-16).  codes_out: m arrays of
  * gulon_coder_bytes(width, n) bytes, back to back ([m][bytesPerCode], the
  * EncodedMatrix.encodings layout, EncodedMatrix.scala:11-23). */
 int32_t gulon_pq_encode(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
                         uint8_t *codes_out);
+/* quantizers [j_begin, j_end) only: codes_out holds (j_end - j_begin) packed arrays back to back */
+int32_t gulon_pq_encode_range(const gulon_dataset *ds, int32_t m, int32_t k, const float *cents,
+                              int32_t j_begin, int32_t j_end, uint8_t *codes_out);
 
 /* ---- Index (Index.scala) ---------------------------------------------------- */
 /* Index.prepareQuery (Index.scala:352-383): t_out[B][m][k]. */

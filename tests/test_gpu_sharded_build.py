@@ -1,0 +1,57 @@
+"""Two ranks (gloo rendezvous, both on the one GPU of the test box) run the quantizer-partitioned
+build and the row-sharded query with the real HIP engine; results must equal the single-process
+build and query bit for bit.  (RCCL refuses two ranks on one device, so the collectives are
+staged through the host here; the device path is what bench.py uses on a multi-GPU node.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gulon_amd as g
+    from gulon_amd.sharded import HipEngine, ShardedIndex, build_sharded
+    n, d, m, k, iters, B, K = 30000, 48, 6, 256, 3, 9, 10
+    dm = g.DeviceMatrix.synthetic(n, d, 3, 77, 30)
+    pq, shard, lo, hi = build_sharded(dm, k, m, iters, rank, world, dist, None)
+    ref_pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, iters))
+    ref_enc = ref_pq.encode(dm)
+    ok = np.array_equal(pq.flat_centroids().view(np.uint32), ref_pq.flat_centroids().view(np.uint32))
+    ok = ok and all(np.array_equal(shard.encodings[j], ref_enc.encodings[j][lo:hi]) for j in range(m))
+    Q = dm.get_rows(np.arange(0, n, n // B, dtype=np.int32)[:B])
+    eng = HipEngine(pq, shard, lo, torch.device("cuda", 0))
+    oi, od, oc, of = ShardedIndex(eng, n, rank, world, dist).batch_query(K, Q)
+    full = g.PQIndex(ref_pq, ref_enc).batch_query_raw(K, Q)
+    ok = ok and np.array_equal(oi, full[0]) and np.array_equal(od.view(np.uint32), full[1].view(np.uint32))
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(int(t.item()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_build_and_query_equal_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1
