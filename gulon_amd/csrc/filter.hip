@@ -1,0 +1,449 @@
+// Quantized lower-bound filter in front of the exact ADC scan (PQIndex.batchQuery,
+// Index.scala:393-440).  Results are the exact path's, bit for bit; only the work changes.
+//
+// The exact scan gathers one fp32 table entry per (query, row, quantizer) from LDS, and the LDS
+// gather bandwidth is what bounds it.  A table entry here is 8 bits, so one
+// ds_read_b128 serves 16 queries instead of 4:
+//
+//   1. an exact scan of a strided sample of the row blocks gives every query a valid upper
+//      bound tau on its final (K+1)-th distance (the (K+1)-th smallest of a subset);
+//   2. per query the fp32 table T_j[c] is quantized DOWNWARDS:
+//        q_j[c] = min(QMAX, floor((T_j[c] - min_j) / delta)),  delta = (tau' - sum_j min_j) / QL,
+//      where tau' = tau * (1 + 2 m u), u = 2^-24, covers the rounding of the reference's
+//      sequential fp32 sum D against the real sum R (all terms >= 0: D >= R (1 - m u)).
+//      Then  sum_j min_j + delta * sum_j q_j[c_j]  <=  R,  and a row with  sum_j q_j > QL  has
+//      R > tau', hence D > tau: it cannot be among the K+1 smallest and is dropped;
+//   3. the (few) surviving (query, row) pairs are queued and re-evaluated with the exact fp32
+//      tables in the reference's summation order, and merged into the running (K+1)-lists under
+//      the same (distance, row id) order as the exact scan.
+//
+// The remaining rows go through two filter stages (a short one that tightens tau, then the
+// rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
+// by the exact scan (per query tile, decided on the device), so the filter never changes a result.
+#include "scan.hpp"
+
+namespace gulon {
+
+namespace {
+
+constexpr size_t FILTER_LDS_BUDGET = 144 * 1024;
+constexpr int FILTER_THREADS = 1024;
+
+__device__ inline uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {   // per 16-bit half: max(a - b, 0)
+  uint32_t d;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// ---- per (query, quantizer) minimum of the fp32 table (NaN entries ignored) ----------------
+__global__ __launch_bounds__(256) void qt_mins(const float4 *__restrict__ tables, int Bp, int m_pad, int k,
+                                               float *__restrict__ mins) {
+  __shared__ unsigned smin[16];
+  const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
+  if (c < 16) smin[c] = 0x7F800000u;
+  __syncthreads();
+#pragma unroll
+  for (int u4 = 0; u4 < 4; u4++) {
+    const int qg4 = g16 * 4 + u4;
+    float4 t = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (qg4 * 4 < Bp && c < k) t = tables[((size_t)qg4 * m_pad + j) * 256 + c];
+    float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float x = v[u] != v[u] ? INFINITY : v[u];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+      if ((c & 63) == 0) atomicMin(&smin[u4 * 4 + u], __float_as_uint(x));   // entries are >= +0: uint order
+    }
+  }
+  __syncthreads();
+  if (c < 16) mins[(size_t)(g16 * 16 + c) * m_pad + j] = __uint_as_float(smin[c]);
+}
+
+// ---- quantize the tables of one 16-query group against the current bounds --------------------
+__global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ tables, int Bp, int m_pad, int k, int B,
+                                                   const float *__restrict__ mins, const float *__restrict__ fin_v,
+                                                   const int *__restrict__ fin_i, int keff, int qmax,
+                                                   uint4 *__restrict__ qtab, int *__restrict__ fb_tile, int qt) {
+  __shared__ double s_delta[16];
+  __shared__ float s_min[16];
+  __shared__ int s_dead[16];
+  const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
+  if (c < 16) {
+    const int q = g16 * 16 + c;
+    int dead = 1;
+    double delta = 1.0;
+    if (q < B) {
+      const float tau = fin_v[(size_t)q * keff + keff - 1];
+      const int ti = fin_i[(size_t)q * keff + keff - 1];
+      if (ti == INT_MAX || !(tau < INFINITY)) {
+        if (j == 0) fb_tile[q / qt] = 1;          // no usable bound: this query is redone exactly
+      } else {
+        double sum_min = 0.0;
+        for (int jj = 0; jj < m_pad; jj++) sum_min += (double)mins[(size_t)q * m_pad + jj];
+        const double taup = (double)tau * (1.0 + 2.0 * m_pad * 5.97e-8) * (1.0 + 1e-9);
+        double budget = taup - sum_min;
+        if (!(budget > 0.0)) budget = 0.0;
+        delta = budget / (double)(qmax - 1);
+        if (delta < 1e-290) delta = 1e-290;
+        dead = 0;
+      }
+    }
+    s_dead[c] = dead;
+    s_delta[c] = delta;
+    s_min[c] = mins[(size_t)q * m_pad + j];
+  }
+  __syncthreads();
+  uint32_t out[4];
+#pragma unroll
+  for (int u4 = 0; u4 < 4; u4++) {
+    const int qg4 = g16 * 4 + u4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool have = qg4 * 4 < Bp && c < k;
+    if (have) t = tables[((size_t)qg4 * m_pad + j) * 256 + c];
+    float v[4] = {t.x, t.y, t.z, t.w};
+    uint32_t word = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int s = u4 * 4 + u;
+      int qv = qmax;
+      if (have && !s_dead[s] && v[u] == v[u]) {
+        double x = ((double)v[u] - (double)s_min[s]) * (1.0 - 8.9e-16);
+        if (x < 0.0) x = 0.0;
+        const double r = x / s_delta[s];
+        if (r < (double)qmax) {
+          qv = (int)r;                                       // floor: r >= 0
+          while (qv > 0 && (double)qv * s_delta[s] > x) qv--;   // guard the rounding of the division
+        }
+      }
+      word |= (uint32_t)qv << (8 * u);
+    }
+    out[u4] = word;
+  }
+  qtab[((size_t)g16 * m_pad + j) * 256 + c] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// ---- the filter: lane = row, 16*NQG queries per workgroup, NADD entries summed per byte -------
+template <int NQG, int VEC, int NADD>
+__global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
+    const uint8_t *__restrict__ codes, int ng, int m_pad, const uint4 *__restrict__ qtab, int row_from, int row_until,
+    int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap) {
+  constexpr int NW = FILTER_THREADS / 64;
+  constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
+  using Word = typename CodeWord<VEC>::type;
+  extern __shared__ uint4 qlds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x, chunk = blockIdx.y;
+  const int tab = m_pad * 256;   // uint4 entries per 16-query group
+  {
+    const int n16 = NQG * tab;
+    const uint4 *src = qtab + (size_t)tile * n16;
+    for (int e = tid; e < n16; e += FILTER_THREADS) qlds[e] = src[e];
+  }
+  __syncthreads();
+
+  const int e0 = chunk * e_per_chunk;
+  const int e1 = min(e_count, e0 + e_per_chunk);
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  int mp_p = (e0 + wave) / mp.width, mp_r = (e0 + wave) - mp_p * mp.width;
+  auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
+  auto advance = [&](int &p, int &r) { r += NW; while (r >= mp.width) { r -= mp.width; p++; } };
+
+  Word w_first{};
+  if (e0 + wave < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+  for (int e = e0 + wave; e < e1; e += NW) {
+    const int rb = block_of(mp_p, mp_r);
+    advance(mp_p, mp_r);
+    const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
+    Word w = w_first;
+    if (e + NW < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+
+    // acc[s][2*dd]   : 16-bit sums of queries 4dd (low half) and 4dd+2 (high half) of group s
+    // acc[s][2*dd+1] : queries 4dd+1 and 4dd+3
+    uint32_t acc[NQG][8];
+#pragma unroll
+    for (int s = 0; s < NQG; s++)
+#pragma unroll
+      for (int x = 0; x < 8; x++) acc[s][x] = 0;
+
+    for (int g = 0; g < ng; g++) {
+      Word wn = w;
+      if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
+      const uint4 *tj = qlds + g * VEC * 256;
+#pragma unroll
+      for (int b = 0; b < VEC; b += NADD) {
+        uint32_t c[NADD];
+#pragma unroll
+        for (int a = 0; a < NADD; a++) c[a] = code_byte<VEC>(w, b + a);
+#pragma unroll
+        for (int s = 0; s < NQG; s++) {
+          uint4 x = tj[b * 256 + c[0] + s * tab];
+#pragma unroll
+          for (int a = 1; a < NADD; a++) {   // bytes cannot carry: NADD * QMAX <= 255
+            const uint4 y = tj[(b + a) * 256 + c[a] + s * tab];
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+          }
+          const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int dd = 0; dd < 4; dd++) {
+            acc[s][2 * dd] += xs[dd] & 0x00FF00FFu;
+            acc[s][2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
+          }
+        }
+      }
+      w = wn;
+    }
+
+    const int row = rb * 64 + lane;
+    const bool valid = row >= row_from && row < row_until;
+    uint32_t any = 0;
+    uint32_t left[NQG][8];
+#pragma unroll
+    for (int s = 0; s < NQG; s++)
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        left[s][x] = pk_sub_sat_u16(QMAXP, acc[s][x]);   // non-zero half <=> that query keeps this row
+        any |= left[s][x];
+      }
+    if (__ballot(valid && any != 0) != 0ull) {
+#pragma unroll
+      for (int s = 0; s < NQG; s++)
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          const uint32_t l = valid ? left[s][x] : 0u;
+          if (__ballot(l != 0) == 0ull) continue;
+          const int q0 = (tile * NQG + s) * 16 + 4 * (x >> 1) + (x & 1);
+          if (l & 0xFFFFu) {
+            const int pos = atomicAdd(&cnt[q0], 1);
+            if (pos < cap) queue[(size_t)q0 * cap + pos] = row;
+          }
+          if (l >> 16) {
+            const int pos = atomicAdd(&cnt[q0 + 2], 1);
+            if (pos < cap) queue[(size_t)(q0 + 2) * cap + pos] = row;
+          }
+        }
+    }
+  }
+}
+
+// ---- exact re-evaluation of the survivors; one wave per query --------------------------------
+template <int VEC>
+__global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict__ codes, int ng, int m_pad,
+                                                       const float *__restrict__ tables, int row_base,
+                                                       int *__restrict__ cnt, const int *__restrict__ queue, int cap,
+                                                       int B, int keff, float *__restrict__ fin_v,
+                                                       int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt) {
+  using Word = typename CodeWord<VEC>::type;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= B) {
+    if (lane == 0) cnt[q] = 0;
+    return;
+  }
+  int n = cnt[q];
+  if (n > cap) {
+    if (lane == 0) fb_tile[q / qt] = 1;   // queue overflow: the exact scan redoes this query tile
+    n = cap;
+  }
+  WaveList wl;
+  wl.v = lane < keff ? fin_v[(size_t)q * keff + lane] : INFINITY;
+  wl.i = lane < keff ? fin_i[(size_t)q * keff + lane] : INT_MAX;
+  wl.tau = readlane_f(wl.v, keff - 1);
+  wl.tau_i = readlane_i(wl.i, keff - 1);
+  // W = 4 interleaved fp32 tables: entry (j, c) of query q at ((q/4 * m_pad + j) * 256 + c) * 4 + q%4
+  const float *tq = tables + (size_t)(q >> 2) * m_pad * 1024 + (q & 3);
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  const int *qq = queue + (size_t)q * cap;
+  for (int base = 0; base < n; base += 64) {
+    const int e = base + lane;
+    const bool have = e < n;
+    const int row = have ? qq[e] : 0;
+    float d = 0.f;                      // the reference's order: j ascending, unfused fp32
+    for (int g = 0; g < ng; g++) {
+      const Word w = cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
+      float t[VEC];
+#pragma unroll
+      for (int b = 0; b < VEC; b++) t[b] = tq[((size_t)(g * VEC + b) * 256 + code_byte<VEC>(w, b)) * 4];
+#pragma unroll
+      for (int b = 0; b < VEC; b++) d += t[b];
+    }
+    const int cr = row + row_base;
+    unsigned long long mk = __ballot(have && wl.accepts(d, cr));
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float v = readlane_f(d, l);
+      const int r = readlane_i(cr, l);
+      if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
+    }
+  }
+  if (lane < keff) {
+    fin_v[(size_t)q * keff + lane] = wl.v;
+    fin_i[(size_t)q * keff + lane] = wl.i;
+  }
+  if (lane == 0) cnt[q] = 0;
+}
+
+template <int NQG, int VEC, int NADD>
+void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
+                     int from, int until, int cap, hipStream_t st) {
+  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * 16;
+  auto kern = filter_kernel<NQG, VEC, NADD>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
+                     reinterpret_cast<const uint4 *>(ix->qtab.p), from, until, rb_begin, e_count, e_per_chunk, mp,
+                     ix->sv_cnt.p, ix->sv_queue.p, cap);
+  HIP_CHECK(hipGetLastError());
+}
+
+int filter_nqg(const gulon_index *ix) { return (size_t)ix->m_pad * 4096 * 2 <= FILTER_LDS_BUDGET ? 2 : 1; }
+
+void launch_filter(gulon_index *ix, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
+                   int e_per_chunk, RbMap mp, int from, int until, int cap, hipStream_t st) {
+#define GO(Q, V, A) launch_filter_t<Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, st)
+  if (ix->vec == 16) {
+    if (nqg == 2) { if (nadd == 4) GO(2, 16, 4); else GO(2, 16, 2); }
+    else          { if (nadd == 4) GO(1, 16, 4); else GO(1, 16, 2); }
+  } else {
+    if (nqg == 2) { if (nadd == 4) GO(2, 4, 4); else GO(2, 4, 2); }
+    else          { if (nadd == 4) GO(1, 4, 4); else GO(1, 4, 2); }
+  }
+#undef GO
+}
+
+}  // namespace
+
+bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
+  const ScanTuning &t = tuning();
+  return t.filter && ix->w == 4 && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 4096 <= FILTER_LDS_BUDGET &&
+         rb_total >= t.filter_min_rb && rb_total >= t.filter_period;
+}
+
+void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
+                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
+  const ScanTuning &t = tuning();
+  const int keff = K + 1;
+  const int QT = 4 * ix->nsub;
+  const int ntiles = ceil_div(B, QT);
+  const int Bp = ntiles * QT;
+  const int nqg = filter_nqg(ix);
+  const int nadd = t.filter_nadd;
+  const int qmax = 255 / nadd;
+  const int ftiles = ceil_div(B, 16 * nqg);
+  const int Bq = ftiles * nqg * 16;
+  const int cap = t.filter_cap;
+  const int rb_begin = from / 64;
+  const int rb_total = ceil_div(until, 64) - rb_begin;
+  const int P = t.filter_period;
+  const int s1 = std::min(t.filter_stage1, P - 2);
+  const RbMap sample{P, 0, 1}, stage1{P, 1, s1}, stage2{P, 1 + s1, P - 1 - s1}, all{1, 0, 1};
+  const int NW = t.threads / 64;
+
+  auto chunking = [&](int e_count, int tiles, int &nchunks, int &per) {
+    int want = ceil_div(t.target_blocks, tiles);
+    int maxc = e_count / (2 * NW);
+    if (maxc < 1) maxc = 1;
+    nchunks = want < maxc ? want : maxc;
+    per = ceil_div(e_count, nchunks);
+    nchunks = ceil_div(e_count, per);
+  };
+
+  // stage 0: exact scan of the sample blocks -> running (K+1)-lists
+  int e0n = rbmap_count(rb_total, sample), c0 = 1, p0 = 1;
+  chunking(e0n, ntiles, c0, p0);
+  const int cfb = std::max(1, ceil_div(256, ntiles));   // fallback: one workgroup per CU when everything is redone
+  const int pfb = ceil_div(rb_total, cfb);
+  const int cfb_n = ceil_div(rb_total, pfb);
+  const int cmax = std::max(c0, cfb_n);
+  ix->tables.ensure((size_t)Bp * ix->m_pad * 256);
+  ix->part_v.ensure((size_t)Bp * cmax * keff);
+  ix->part_i.ensure((size_t)Bp * cmax * keff);
+  ix->gtau.ensure((size_t)Bp);
+  ix->fin_v.ensure((size_t)Bq * keff);
+  ix->fin_i.ensure((size_t)Bq * keff);
+  ix->qmins.ensure((size_t)Bq * ix->m_pad);
+  ix->qtab.ensure((size_t)(Bq / 16) * ix->m_pad * 256 * 16);
+  ix->sv_cnt.ensure((size_t)Bq);
+  ix->sv_queue.ensure((size_t)Bq * cap);
+  ix->fb_tile.ensure((size_t)ntiles);
+  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
+  HIP_CHECK(hipMemsetAsync(ix->fb_tile.p, 0, sizeof(int) * (size_t)ntiles, st));
+  HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Bq, st));
+
+  launch_build_tables(4, ix, dQ, B, Bp, ix->tables.p, st);
+  launch_scan(ix, ntiles, c0, rb_begin, e0n, p0, sample, from, until, keff, st);
+  launch_merge(false, ix->part_v.p, ix->part_i.p, c0, (long long)keff, (long long)c0 * keff, B, K, nullptr, nullptr,
+               nullptr, nullptr, ix->fin_v.p, ix->fin_i.p, st);
+  hipLaunchKernelGGL(qt_mins, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
+                     reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, ix->qmins.p);
+  HIP_CHECK(hipGetLastError());
+
+  const bool stats = getenv("GULON_FILTER_STATS") != nullptr;
+  const RbMap stages[2] = {stage1, stage2};
+  for (int sidx = 0; sidx < 2; sidx++) {
+    const RbMap mp = stages[sidx];
+    const int en = rbmap_count(rb_total, mp);
+    if (en <= 0) continue;
+    int nc = 1, per = 1;
+    chunking(en, ftiles, nc, per);
+    hipLaunchKernelGGL(qt_quantize, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, B, ix->qmins.p,
+                       ix->fin_v.p, ix->fin_i.p, keff, qmax, reinterpret_cast<uint4 *>(ix->qtab.p), ix->fb_tile.p, QT);
+    HIP_CHECK(hipGetLastError());
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ix->profile) {
+      HIP_CHECK(hipEventCreate(&ev0));
+      HIP_CHECK(hipEventCreate(&ev1));
+      HIP_CHECK(hipEventRecord(ev0, st));
+    }
+    launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, st);
+    if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<int> h((size_t)Bq);
+      HIP_CHECK(hipMemcpy(h.data(), ix->sv_cnt.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+      long long tot = 0; int mx = 0;
+      for (int v : h) { tot += v; mx = std::max(mx, v); }
+      fprintf(stderr, "[filter] stage %d: %d row blocks, %d x %d workgroups, survivors total %lld (%.3g of pairs), "
+              "max per query %d (cap %d)\n", sidx + 1, en, ftiles, nc, tot, (double)tot / ((double)en * 64 * B), mx, cap);
+    }
+    if (ix->profile) {
+      HIP_CHECK(hipEventRecord(ev1, st));
+      ix->events.emplace_back(ev0, ev1);
+      ix->prof_rows += std::min<long long>((long long)en * 64, (long long)until - from);
+    }
+    if (ix->vec == 16)
+      hipLaunchKernelGGL(survivors_kernel<16>, dim3(Bq), dim3(64), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
+                         ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
+                         ix->fb_tile.p, QT);
+    else
+      hipLaunchKernelGGL(survivors_kernel<4>, dim3(Bq), dim3(64), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
+                         ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
+                         ix->fb_tile.p, QT);
+    HIP_CHECK(hipGetLastError());
+  }
+
+  // fallback (device-side decision): flagged query tiles are rescanned exactly over all rows
+  launch_scan(ix, ntiles, cfb_n, rb_begin, rb_total, pfb, all, from, until, keff, st, nullptr, nullptr, ix->fb_tile.p);
+  launch_merge_enabled(ix->part_v.p, ix->part_i.p, cfb_n, (long long)keff, (long long)cfb_n * keff, B, K, ix->fin_v.p,
+                       ix->fin_i.p, ix->fb_tile.p, QT, st);
+
+  if (stats) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<int> h((size_t)ntiles);
+    HIP_CHECK(hipMemcpy(h.data(), ix->fb_tile.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    int nfb = 0;
+    for (int v : h) nfb += v != 0;
+    fprintf(stderr, "[filter] %d of %d query tiles redone by the exact scan\n", nfb, ntiles);
+  }
+  int *flags = d_of;
+  if (final_out && replay_enabled() && flags == nullptr) {
+    ix->flags_scratch.ensure((size_t)B);
+    flags = ix->flags_scratch.p;
+  }
+  launch_merge(final_out, ix->fin_v.p, ix->fin_i.p, 1, 0LL, (long long)keff, B, K, d_oi, d_od, d_oc, flags, d_pv, d_pi,
+               st);
+  if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
+}
+
+}  // namespace gulon

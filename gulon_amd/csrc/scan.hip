@@ -113,20 +113,6 @@ __global__ void build_tables(const float *__restrict__ cents, const int *__restr
 // LDS holds NSUB interleaved tables ([j][c] -> float4 of 4 queries); lane = row;
 // every (row, quantizer) costs one ds_read_b128 per sub-table and 4 adds.
 // ---------------------------------------------------------------------------
-template <int VEC> struct CodeWord;
-template <> struct CodeWord<4> { using type = uint32_t; };
-template <> struct CodeWord<16> { using type = uint4; };
-
-template <int VEC>
-__device__ inline uint32_t code_byte(const typename CodeWord<VEC>::type &w, int b);
-template <>
-__device__ inline uint32_t code_byte<4>(const uint32_t &w, int b) { return (w >> (8 * b)) & 0xFFu; }
-template <>
-__device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
-  uint32_t x = (b < 4) ? w.x : (b < 8) ? w.y : (b < 12) ? w.z : w.w;
-  return (x >> (8 * (b & 3))) & 0xFFu;
-}
-
 // W queries are interleaved per table entry: W = 4 -> ds_read_b128, 2 -> b64, 1 -> b32.
 template <int W> struct TabVec;
 template <> struct TabVec<4> { using type = float4; };
@@ -136,11 +122,12 @@ template <> struct TabVec<1> { using type = float; };
 template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
 __global__ __launch_bounds__(THREADS) void scan_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
-    int row_from, int row_until, int row_base, int rb_begin, int rb_end, int rb_per_chunk, int nchunks,
+    int row_from, int row_until, int row_base, int rb_begin, int e_count, int e_per_chunk, RbMap mp, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
     int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi,
-    unsigned long long *__restrict__ dbg) {
+    const int *__restrict__ tile_enable, unsigned long long *__restrict__ dbg) {
   constexpr int QT = W * NSUB;
+  if (tile_enable && tile_enable[blockIdx.x] == 0) return;   // filter fallback: only flagged query tiles
   // optional timeline (GULON_SCAN_TIMELINE=1): 4 stamps per workgroup, 100 MHz wall clock
   if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = wall_clock64();
   constexpr int NW = THREADS / 64;
@@ -151,7 +138,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x;   // query tile (fastest: tiles of one chunk run together)
   const int chunk = blockIdx.y;
   const int tab_entries = m_pad * 256;  // entries (of W floats) per sub-table
@@ -189,22 +176,29 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
     lbiq[q] = peel ? lbi[tile * QT + q] : -1;
   }
 
-  const int rb0 = rb_begin + chunk * rb_per_chunk;
-  const int rb1 = min(rb_end, rb0 + rb_per_chunk);
+  // this chunk's share of the eligible row blocks, in e-space (RbMap); (mp_p, mp_r) tracks
+  // e = mp_p * width + mp_r without a division per row block
+  const int e0 = chunk * e_per_chunk;
+  const int e1 = min(e_count, e0 + e_per_chunk);
   const Word *cw = reinterpret_cast<const Word *>(codes);
+  int mp_p = (e0 + wave) / mp.width, mp_r = (e0 + wave) - mp_p * mp.width;
+  auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
+  auto advance = [&](int &p, int &r) { r += NW; while (r >= mp.width) { r -= mp.width; p++; } };
 
   // software pipeline: the first code word of the NEXT row block is in flight while this
   // one is being looked up (global latency would otherwise idle the LDS pipe)
   Word w_first{};
-  if (rb0 + wave < rb1) w_first = cw[((size_t)(rb0 + wave) * ng) * 64 + lane];
-  for (int rb = rb0 + wave; rb < rb1; rb += NW) {
+  if (e0 + wave < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+  for (int e = e0 + wave; e < e1; e += NW) {
+    const int rb = block_of(mp_p, mp_r);
+    advance(mp_p, mp_r);
     float acc[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) acc[q] = 0.f;
 
     const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
     Word w = w_first;
-    if (rb + NW < rb1) w_first = cw[((size_t)(rb + NW) * ng) * 64 + lane];
+    if (e + NW < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
 
     // workgroup-shared thresholds (wave-uniform LDS reads); <= keeps exact-tie candidates
     float tsh[QT];
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
       }
     }
     // every 32 row blocks one wave trades thresholds with the other workgroups of this tile
-    if (wave == 0 && (((rb - rb0) / NW) & 31) == 31 && lane < QT) {
+    if (wave == 0 && (((e - e0) / NW) & 31) == 31 && lane < QT) {
       unsigned mine = __hip_atomic_load(&tau_sh[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       unsigned old = __hip_atomic_fetch_min(&gtau[tile * QT + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old < mine)
@@ -342,10 +336,12 @@ __global__ __launch_bounds__(64) void merge_lists(const float *__restrict__ in_v
                                                   int B, int K, int keff, int *__restrict__ out_idx,
                                                   float *__restrict__ out_dist, int *__restrict__ out_count,
                                                   int *__restrict__ out_flags, float *__restrict__ out_pv,
-                                                  int *__restrict__ out_pi) {
+                                                  int *__restrict__ out_pi, const int *__restrict__ tile_enable,
+                                                  int qt) {
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   if (q >= B) return;
+  if (tile_enable && tile_enable[q / qt] == 0) return;
   WaveList wl;
   wl.init();
   const int total = lists * keff;
@@ -396,10 +392,6 @@ __global__ __launch_bounds__(64) void merge_lists(const float *__restrict__ in_v
   }
 }
 
-template __global__ void merge_lists<true>(const float *, const int *, int, long long, long long, int, int, int,
-                                           int *, float *, int *, int *, float *, int *);
-template __global__ void merge_lists<false>(const float *, const int *, int, long long, long long, int, int, int,
-                                            int *, float *, int *, int *, float *, int *);
 
 void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists, long long stride_l,
                   long long stride_q, int B, int K, int *out_idx, float *out_dist, int *out_count,
@@ -408,10 +400,18 @@ void launch_merge(bool final_out, const float *in_v, const int *in_i, int lists,
   int keff = K + 1;
   if (final_out)
     hipLaunchKernelGGL(merge_lists<true>, dim3(B), dim3(64), 0, st, in_v, in_i, lists, stride_l, stride_q, B, K,
-                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi);
+                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi, (const int *)nullptr, 1);
   else
     hipLaunchKernelGGL(merge_lists<false>, dim3(B), dim3(64), 0, st, in_v, in_i, lists, stride_l, stride_q, B, K,
-                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi);
+                       keff, out_idx, out_dist, out_count, out_flags, out_pv, out_pi, (const int *)nullptr, 1);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long long stride_l, long long stride_q, int B,
+                          int K, float *out_pv, int *out_pi, const int *tile_enable, int qt, hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(merge_lists<false>, dim3(B), dim3(64), 0, st, in_v, in_i, lists, stride_l, stride_q, B, K, K + 1,
+                     (int *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, out_pv, out_pi, tile_enable, qt);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -475,6 +475,31 @@ void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpa
   HIP_CHECK(hipGetLastError());
 }
 
+ScanTuning::ScanTuning() {
+  static const char *keys[] = {"GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE", "GULON_SCAN_PRUNE_FROM", "GULON_SCAN_FILTER",
+                               "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
+                               "GULON_FILTER_NADD"};
+  for (const char *k : keys)
+    if (const char *e = getenv(k)) set(k, atoi(e));
+}
+
+bool ScanTuning::set(const char *key, int v) {
+  std::string k(key);
+  if (k == "GULON_SCAN_BLOCKS") { if (v >= 1) target_blocks = v; }
+  else if (k == "GULON_SCAN_PRUNE") prune = v != 0;
+  else if (k == "GULON_SCAN_PRUNE_FROM") prune_from = v;
+  else if (k == "GULON_SCAN_FILTER") filter = v != 0;
+  else if (k == "GULON_FILTER_MIN_RB") filter_min_rb = v < 4 ? 4 : v;
+  else if (k == "GULON_FILTER_PERIOD") { if (v >= 3) filter_period = v; }
+  else if (k == "GULON_FILTER_STAGE1") { if (v >= 1) filter_stage1 = v; }
+  else if (k == "GULON_FILTER_CAP") { if (v >= 64) filter_cap = v; }
+  else if (k == "GULON_FILTER_NADD") { if (v == 2 || v == 4) filter_nadd = v; }
+  else return false;
+  return true;
+}
+
+ScanTuning &tuning() { static ScanTuning t; return t; }
+
 bool replay_enabled() {
   static const bool on = [] { const char *e = getenv("GULON_TIE_REPLAY"); return !(e && atoi(e) == 0); }();
   return on;
@@ -491,23 +516,10 @@ namespace {
 
 constexpr size_t LDS_BUDGET = 144 * 1024;
 
-// launch shape knobs (environment overrides are for tuning experiments only)
-struct ScanTuning {
-  int threads = 1024;       // workgroup size (16 waves hide the pruning checkpoints' LDS drain)
-  int target_blocks = 4096; // workgroups per launch aimed for
-  int prune = 1;            // exact early termination on/off
-  int prune_from = -1;      // first quantizer index with a pruning checkpoint (-1: m_pad/2)
-  ScanTuning() {
-    if (const char *e = getenv("GULON_SCAN_BLOCKS")) { int v = atoi(e); if (v >= 1) target_blocks = v; }
-    if (const char *e = getenv("GULON_SCAN_PRUNE")) prune = atoi(e) != 0;
-    if (const char *e = getenv("GULON_SCAN_PRUNE_FROM")) prune_from = atoi(e);
-  }
-};
-static const ScanTuning &tuning() { static ScanTuning t; return t; }
-
 template <int W, int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
-void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                   int until, int keff, hipStream_t st, const float *lbv, const int *lbi) {
+void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
+                   int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
+                   const int *tile_enable) {
   size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * W * sizeof(float);
   size_t merge_bytes = (size_t)W * NSUB * (SCAN_THREADS / 64) * 64 * 8;
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
@@ -516,7 +528,7 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
   int prune_from = tuning().prune_from >= 0 ? tuning().prune_from : ix->m_pad / 2;
   if (prune_from < 4) prune_from = 4;
   unsigned long long *dbg = nullptr;
-  if (getenv("GULON_SCAN_TIMELINE")) {
+  if (getenv("GULON_SCAN_TIMELINE") && !tile_enable) {
     ix->dbg.ensure((size_t)ntiles * nchunks * 4);
     dbg = ix->dbg.p;
   }
@@ -524,9 +536,9 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
-                     reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, rb_end,
-                     rb_per_chunk, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
-                     lbi, dbg);
+                     reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, e_count,
+                     e_per_chunk, mp, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
+                     lbi, tile_enable, dbg);
   HIP_CHECK(hipGetLastError());
   if (dbg) {   // debugging aid: synchronous dump of the per-workgroup timeline
     HIP_CHECK(hipStreamSynchronize(st));
@@ -551,21 +563,27 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int r
 }
 
 template <int W, int NSUB, int VEC>
-void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                   int until, int keff, hipStream_t st, const float *lbv, const int *lbi) {
+void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
+                   int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
+                   const int *tile_enable) {
   constexpr int TH = 1024;
   if (tuning().prune)
-    launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st,
-                                          lbv, lbi);
+    launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff,
+                                          st, lbv, lbi, tile_enable);
   else
-    launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st,
-                                           lbv, lbi);
+    launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff,
+                                           st, lbv, lbi, tile_enable);
 }
 
-void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_end, int rb_per_chunk, int from,
-                 int until, int keff, hipStream_t st, const float *lbv = nullptr, const int *lbi = nullptr) {
-#define GO(WW, NS, V) \
-  launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st, lbv, lbi)
+}  // namespace
+
+namespace gulon {
+void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
+                 int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
+                 const int *tile_enable) {
+#define GO(WW, NS, V)                                                                                          \
+  launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff, st, lbv, lbi, \
+                           tile_enable)
   if (ix->w == 4) {
     if (ix->vec == 16) {
       if (ix->nsub == 4) GO(4, 4, 16); else if (ix->nsub == 2) GO(4, 2, 16); else GO(4, 1, 16);
@@ -579,6 +597,9 @@ void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int rb_
   }
 #undef GO
 }
+}  // namespace gulon
+
+namespace {
 
 // Enqueue table build + scan + merge.  Exactly one of (final outputs) / (partial outputs) is used.
 void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
@@ -629,6 +650,11 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   nchunks = ceil_div(rb_total, rb_per_chunk);
 
   const int Bp = ntiles * QT;
+  const RbMap all{1, 0, 1};
+  if (!peeled && filter_eligible(ix, K, rb_total)) {
+    run_filter_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st);
+    return;
+  }
   if (peeled) {
     launch_build_tables(W, ix, dQ, B, Bp, (ix->tables.ensure((size_t)Bp * ix->m_pad * 256), ix->tables.p), st);
     const int rounds = ceil_div(K + 1, 64), cap = rounds * 64;
@@ -642,7 +668,7 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->peel_lbi.p, 0xFFFFFFFF /* -1 */, (size_t)Bp, st));
     for (int r = 0; r < rounds; r++) {
       HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
-      launch_scan(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, 64, st, ix->peel_lbv.p,
+      launch_scan(ix, ntiles, nchunks, rb_begin, rb_total, rb_per_chunk, all, from, until, 64, st, ix->peel_lbv.p,
                   ix->peel_lbi.p);
       launch_merge(false, ix->part_v.p, ix->part_i.p, nchunks, 64LL, (long long)nchunks * 64, B, 63, nullptr, nullptr,
                    nullptr, nullptr, ix->peel_tv.p, ix->peel_ti.p, st);
@@ -667,10 +693,11 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     HIP_CHECK(hipEventCreate(&e1));
     HIP_CHECK(hipEventRecord(e0, st));
   }
-  launch_scan(ix, ntiles, nchunks, rb_begin, rb_end, rb_per_chunk, from, until, keff, st);
+  launch_scan(ix, ntiles, nchunks, rb_begin, rb_total, rb_per_chunk, all, from, until, keff, st);
   if (ix->profile) {
     HIP_CHECK(hipEventRecord(e1, st));
     ix->events.emplace_back(e0, e1);
+    ix->prof_rows += until - from;
   }
   int *flags = d_of;
   if (final_out && replay_enabled() && flags == nullptr) {   // the replay needs the tie flags even if the caller does not
@@ -813,6 +840,7 @@ GULON_API int32_t gulon_index_profile(gulon_index *idx, int32_t enable) {
     std::lock_guard<std::mutex> lock(idx->mu);
     for (auto &e : idx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     idx->events.clear();
+    idx->prof_rows = 0;
     idx->profile = enable != 0;
   });
 }
@@ -830,6 +858,19 @@ GULON_API int32_t gulon_index_profile_read(gulon_index *idx, double *scan_ms_tot
     }
     if (scan_ms_total) *scan_ms_total = tot;
     if (launches) *launches = (int32_t)idx->events.size();
+  });
+}
+
+GULON_API int32_t gulon_index_profile_read_ex(gulon_index *idx, double *ms_total, int32_t *launches,
+                                              int64_t *rows_total) {
+  int32_t rc = gulon_index_profile_read(idx, ms_total, launches);
+  if (rc == GULON_OK && rows_total) *rows_total = idx->prof_rows;
+  return rc;
+}
+
+GULON_API int32_t gulon_scan_tuning(const char *key, int32_t value) {
+  return guarded([&] {
+    GULON_REQUIRE(key != nullptr && tuning().set(key, value), "unknown tuning key");
   });
 }
 

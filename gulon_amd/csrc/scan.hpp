@@ -45,8 +45,13 @@ struct gulon_index {
   // exact tie replay (replay.hip)
   DevBuf<int> rp_list, rp_count, rp_segcnt, rp_evcnt, rp_overflow, rp_evi, rp_precnt;
   DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv;
-  // optional hipEvent bracketing of the scan kernel (bench.py roofline line)
+  // quantized lower-bound filter (filter.hip)
+  DevBuf<float> fin_v, qmins;       // running exact (K+1)-lists [Bq][keff]; per (query, quantizer) table minima
+  DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;
+  DevBuf<uint8_t> qtab;             // [Bq/16][m_pad][256][16] quantized table entries
+  // optional hipEvent bracketing of the dominant scan kernel (bench.py roofline line)
   bool profile = false;
+  long long prof_rows = 0;          // rows covered by the bracketed launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::mutex mu;
   ~gulon_index() {
@@ -56,6 +61,60 @@ struct gulon_index {
 
 
 namespace gulon {
+// Strided selection of row blocks: the e-th eligible block (relative to the first block of the
+// scanned range) is (e / width) * period + lo + e % width.  {1, 0, 1} = every block.
+struct RbMap { int period, lo, width; };
+inline int rbmap_count(int rb_total, RbMap mp) {
+  int extra = rb_total % mp.period - mp.lo;
+  extra = extra < 0 ? 0 : extra > mp.width ? mp.width : extra;
+  return (rb_total / mp.period) * mp.width + extra;
+}
+
+// launch shape knobs (environment overrides / gulon_scan_tuning are for experiments and tests)
+struct ScanTuning {
+  int threads = 1024;        // workgroup size (16 waves hide the pruning checkpoints' LDS drain)
+  int target_blocks = 4096;  // workgroups per launch aimed for
+  int prune = 1;             // exact early termination on/off
+  int prune_from = -1;       // first quantizer index with a pruning checkpoint (-1: m_pad/2)
+  int filter = 1;            // quantized lower-bound filter on/off
+  int filter_min_rb = 8192;  // smallest range (in 64-row blocks) the filter is used for
+  int filter_period = 128;   // row blocks per sampling period
+  int filter_stage1 = 12;    // blocks per period scanned by the first (loose) filter stage
+  int filter_cap = 32768;    // survivor queue entries per query and stage
+  int filter_nadd = 2;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels)
+  ScanTuning();
+  bool set(const char *key, int v);
+};
+ScanTuning &tuning();
+
+// scan.hip: exact scan of the selected row blocks of [from, until) into ix->part_v/part_i
+// ([query][nchunks][keff]); tile_enable (device, per query tile) skips disabled tiles.
+void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
+                 int from, int until, int keff, hipStream_t st, const float *lbv = nullptr, const int *lbi = nullptr,
+                 const int *tile_enable = nullptr);
+// merge_lists<false> restricted to the queries of enabled tiles (fallback of the filter)
+void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long long stride_l, long long stride_q, int B,
+                          int K, float *out_pv, int *out_pi, const int *tile_enable, int qt, hipStream_t st);
+// filter.hip: sample scan -> quantized filter stages -> exact re-evaluation of the survivors.
+bool filter_eligible(const gulon_index *ix, int K, int rb_total);
+void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
+                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st);
+
+#ifdef __HIPCC__
+template <int VEC> struct CodeWord;
+template <> struct CodeWord<4> { using type = uint32_t; };
+template <> struct CodeWord<16> { using type = uint4; };
+template <int VEC>
+__device__ inline uint32_t code_byte(const typename CodeWord<VEC>::type &w, int b);
+template <>
+__device__ inline uint32_t code_byte<4>(const uint32_t &w, int b) { return (w >> (8 * b)) & 0xFFu; }
+template <>
+__device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
+  uint32_t x = (b < 4) ? w.x : (b < 8) ? w.y : (b < 12) ? w.z : w.w;
+  return (x >> (8 * (b & 3))) & 0xFFu;
+}
+#endif
+
 // Index.prepareQuery tables, W queries interleaved (scan.hip)
 void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
                          const int *live_queries = nullptr);

@@ -188,6 +188,14 @@ int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, i
  * gulon_index_profile_read synchronises them and returns the summed duration. */
 int32_t gulon_index_profile(gulon_index *idx, int32_t enable);
 int32_t gulon_index_profile_read(gulon_index *idx, double *scan_ms_total, int32_t *launches);
+/* Same, plus the number of rows the bracketed launches covered (the dominant kernel is the
+ * quantized filter when it is active, the exact scan otherwise). */
+int32_t gulon_index_profile_read_ex(gulon_index *idx, double *ms_total, int32_t *launches, int64_t *rows_total);
+/* Launch-shape / algorithm knobs of the scan, process-wide (tests and tuning experiments):
+ * key = the name of the corresponding environment variable, e.g. "GULON_SCAN_FILTER" (0/1),
+ * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
+ * "GULON_FILTER_NADD", "GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE".  Results never depend on them. */
+int32_t gulon_scan_tuning(const char *key, int32_t value);
 /* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
  * the deterministic (distance, row id) order: merges `lists` partial lists per
  * query, laid out [lists][B][K+1], into the final K.  list_stride = elements

@@ -1,0 +1,175 @@
+"""GPU parity tests for the quantized lower-bound filter in front of the ADC scan (filter.hip).
+
+The filter only changes how much work is done, never a result: everything here must equal the
+CPU oracle bit for bit, exactly as the unfiltered scan does.  The filter is normally reserved for
+large row ranges; the tuning knobs shrink its thresholds so that small, oracle-sized cases run
+through every stage (sample scan, two filter stages, survivor re-evaluation, fallback)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+from test_gpu_query import _check, _make
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_MIN_RB": 8192, "GULON_FILTER_PERIOD": 128,
+            "GULON_FILTER_STAGE1": 12, "GULON_FILTER_CAP": 32768, "GULON_FILTER_NADD": 2}
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gulon_amd
+    assert gulon_amd.native.device_count() >= 1
+    return gulon_amd
+
+
+@pytest.fixture
+def tune(g):
+    from gulon_amd import native as N
+
+    def set_(**kw):
+        for k, v in kw.items():
+            N.check(N.lib().gulon_scan_tuning(k.encode(), int(v)))
+    set_(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE1=2)
+    yield set_
+    set_(**DEFAULTS)
+
+
+def test_tuning_rejects_unknown_key(g):
+    from gulon_amd import native as N
+    assert N.lib().gulon_scan_tuning(b"GULON_NO_SUCH_KNOB", 1) != 0
+
+
+@pytest.mark.parametrize("nadd", [2, 4])
+@pytest.mark.parametrize("n,d,m,k,B,K,frm,until", [
+    (100000, 128, 16, 256, 37, 10, 0, None),        # BASELINE shape: 2 groups of 16 queries per workgroup
+    (60000, 128, 16, 256, 100, 10, 0, None),        # several filter tiles, ragged last one
+    (30000, 100, 25, 256, 9, 10, 0, None),          # ragged m: 4-byte code words, one group per workgroup
+    (40000, 64, 32, 256, 20, 5, 0, None),           # m = 32: two 16-byte code words per row
+    (40000, 32, 8, 256, 33, 1, 0, None),            # K = 1
+    (20000, 12, 4, 5, 3, 20, 0, None),              # width-4 codes, k = 5
+    (20000, 8, 8, 1, 2, 7, 0, None),                # k = 1: every row has the same distance
+    (20000, 16, 4, 3, 4, 63, 0, None),              # width-2 codes, max K
+    (50000, 128, 16, 256, 8, 10, 12345, 40001),     # from/until sub-range (partial first and last block)
+    (20000, 72, 36, 256, 5, 10, 0, None),           # widest table the filter takes (m_pad = 36)
+])
+def test_filtered_query_bit_exact(oracle, g, tune, n, d, m, k, B, K, frm, until, nadd):
+    tune(GULON_FILTER_NADD=nadd)
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + d)
+    Q = np.random.default_rng(7).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q, frm, until)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    _check(oracle, res, oi, od, oc)
+    ix.close()
+
+
+def test_filter_equals_unfiltered_scan(oracle, g, tune):
+    """Same index, same queries: filter on vs off give identical ids, distances and flags."""
+    n, d, m, k, B, K = 200000, 128, 16, 256, 64, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=5)
+    Q = np.random.default_rng(11).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    a = ix.batch_query(K, Q)
+    tune(GULON_SCAN_FILTER=0)
+    b = ix.batch_query(K, Q)
+    for x, y in zip(a, b):
+        assert x.rows.tolist() == y.rows.tolist()
+        assert np.array_equal(bits(x.distances), bits(y.distances))
+        assert x.flags == y.flags
+    ix.close()
+
+
+def test_queries_that_are_dataset_rows(oracle, g, tune):
+    """A query equal to a centroid combination has distance == sum of the table minima (budget 0)."""
+    n, d, m, k, B, K = 50000, 64, 16, 256, 12, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=21)
+    from gulon_amd.vectors import subvector_bounds
+    fr, un = subvector_bounds(d, m)
+    Q = np.zeros((B, d), np.float32)
+    for q in range(B):           # decode row q: its ADC distance to itself is exactly 0
+        for j in range(m):
+            s = un[j] - fr[j]
+            c = idx[j, q]
+            Q[q, fr[j]:un[j]] = cents[k * fr[j] + c * s: k * fr[j] + (c + 1) * s]
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    _check(oracle, res, oi, od, oc)
+    assert all(r.distances[0] == 0.0 for r in res)
+    ix.close()
+
+
+def test_ties_are_flagged_and_replayed(oracle, g, tune):
+    n, d, m, k, B, K = 60000, 128, 16, 256, 10, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=3, dup=3000)
+    Q = np.random.default_rng(2).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    _check(oracle, res, oi, od, oc)
+    ix.close()
+
+
+def test_queue_overflow_falls_back_to_exact_scan(oracle, g, tune):
+    """A 64-entry survivor queue overflows for every query; the device-side fallback redoes them."""
+    tune(GULON_FILTER_CAP=64)
+    n, d, m, k, B, K = 80000, 32, 8, 16, 21, 10          # few centroids: coarse distances, many survivors
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=9)
+    Q = np.random.default_rng(4).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    _check(oracle, res, oi, od, oc)
+    ix.close()
+
+
+def test_nan_and_huge_queries(oracle, g, tune):
+    n, d, m, k, B, K = 30000, 64, 16, 256, 6, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=13)
+    Q = np.random.default_rng(5).standard_normal((B, d)).astype(np.float32)
+    Q[1, 3] = np.nan            # every distance NaN: nothing is returned
+    Q[4, :] = 1e30              # every distance overflows to +inf
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    for q in (0, 2, 3, 5):
+        assert res[q].rows.tolist() == oi[q, :oc[q]].tolist()
+        assert np.array_equal(bits(res[q].distances), bits(od[q, :oc[q]]))
+    assert len(res[1]) == 0
+    ix.close()
+
+
+def test_sharded_partial_lists_through_the_filter(oracle, g, tune):
+    """Row shards scanned with the filter, merged: equals the single-index result."""
+    import ctypes as C
+    from gulon_amd import native as N
+    from gulon_amd.sharded import local_shard
+    n, d, m, k, B, K = 90000, 128, 16, 256, 19, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=17)
+    Q = np.random.default_rng(6).standard_normal((B, d)).astype(np.float32)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    L = N.lib()
+    bounds = [0, 30000, 61111, n]
+    pd, pi = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ix = g.PQIndex(pq, local_shard(pq, enc, lo, hi), row_base=lo)
+        dq, dv, di = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(L.gulon_dev_malloc(C.byref(dq), Q.nbytes))
+        N.check(L.gulon_dev_malloc(C.byref(dv), B * (K + 1) * 4))
+        N.check(L.gulon_dev_malloc(C.byref(di), B * (K + 1) * 4))
+        N.check(L.gulon_memcpy_h2d(dq, Q.ctypes.data_as(C.c_void_p), Q.nbytes))
+        N.check(L.gulon_index_scan_partial_dev(ix._h, dq, B, K, 0, hi - lo, dv, di, None))
+        N.check(L.gulon_device_synchronize())
+        v = np.zeros((B, K + 1), np.float32)
+        i = np.zeros((B, K + 1), np.int32)
+        N.check(L.gulon_memcpy_d2h(v.ctypes.data_as(C.c_void_p), dv, v.nbytes))
+        N.check(L.gulon_memcpy_d2h(i.ctypes.data_as(C.c_void_p), di, i.nbytes))
+        for p_ in (dq, dv, di):
+            N.check(L.gulon_dev_free(p_))
+        pd.append(v)
+        pi.append(i)
+        ix.close()
+    from gulon_amd.topk import merge_partials
+    out_i, out_d, out_c, out_f = merge_partials(np.stack(pd), np.stack(pi), K)
+    assert np.array_equal(out_i, oi) and np.array_equal(bits(out_d), bits(od))
