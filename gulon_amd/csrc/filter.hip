@@ -5,7 +5,7 @@
 // gather bandwidth is what bounds it.  A table entry here is 8 bits, so one
 // ds_read_b128 serves 16 queries instead of 4:
 //
-//   1. an exact scan of a strided sample of the row blocks gives every query a valid upper
+//   1. the exact distances of a few thousand strided sample rows give every query a valid upper
 //      bound tau on its final (K+1)-th distance (the (K+1)-th smallest of a subset);
 //   2. per query the fp32 table T_j[c] is quantized DOWNWARDS:
 //        q_j[c] = min(QMAX, floor((T_j[c] - min_j) / delta)),  delta = (tau' - sum_j min_j) / QL,
@@ -17,8 +17,8 @@
 //      tables in the reference's summation order, and merged into the running (K+1)-lists under
 //      the same (distance, row id) order as the exact scan.
 //
-// The remaining rows go through two filter stages (a short one that tightens tau, then the
-// rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
+// The rows go through three filter stages over disjoint, strided sets of row blocks (two short
+// ones that tighten tau, then the rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
 // by the exact scan (per query tile, decided on the device), so the filter never changes a result.
 #include "scan.hpp"
 
@@ -28,6 +28,7 @@ namespace {
 
 constexpr size_t FILTER_LDS_BUDGET = 144 * 1024;
 constexpr int FILTER_THREADS = 1024;
+constexpr int NSLOT = 16;   // survivor sub-queues per query (workgroups of different chunks use different ones)
 
 __device__ inline uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {   // per 16-bit half: max(a - b, 0)
   uint32_t d;
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void qt_mins(const float4 *__restrict__ tables
 // ---- quantize the tables of one 16-query group against the current bounds --------------------
 __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ tables, int Bp, int m_pad, int k, int B,
                                                    const float *__restrict__ mins, const float *__restrict__ fin_v,
-                                                   const int *__restrict__ fin_i, int keff, int qmax,
-                                                   uint4 *__restrict__ qtab, int *__restrict__ fb_tile, int qt) {
+                                                   const int *__restrict__ fin_i, const float *__restrict__ tau0,
+                                                   int keff, int qmax, uint4 *__restrict__ qtab,
+                                                   int *__restrict__ fb_tile, int qt) {
   __shared__ double s_delta[16];
   __shared__ float s_min[16];
   __shared__ int s_dead[16];
@@ -74,9 +76,10 @@ __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ ta
     int dead = 1;
     double delta = 1.0;
     if (q < B) {
-      const float tau = fin_v[(size_t)q * keff + keff - 1];
-      const int ti = fin_i[(size_t)q * keff + keff - 1];
-      if (ti == INT_MAX || !(tau < INFINITY)) {
+      // bound = the sample's, tightened by the running list once that is full
+      float tau = tau0[q];
+      if (fin_i[(size_t)q * keff + keff - 1] != INT_MAX) tau = fminf(tau, fin_v[(size_t)q * keff + keff - 1]);
+      if (!(tau < INFINITY)) {
         if (j == 0) fb_tile[q / qt] = 1;          // no usable bound: this query is redone exactly
       } else {
         double sum_min = 0.0;
@@ -123,11 +126,107 @@ __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ ta
   qtab[((size_t)g16 * m_pad + j) * 256 + c] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// ---- initial bounds from a strided sample of row blocks ---------------------------------------
+// One workgroup per 4 queries, their float4-interleaved fp32 table in LDS, lane = row as in the
+// exact scan -- but no top-k lists in the loop: every lane only keeps the minimum exact distance
+// of the rows it saw (1024 disjoint groups of rows per workgroup).  Any K+1 group minima belong
+// to K+1 distinct rows, so the (K+1)-th smallest group minimum bounds the final (K+1)-th
+// distance from above; with 1024 groups it is almost always the sample's own (K+1)-th distance.
+// Selection = one 64-lane bitonic sort per wave and query, then a sorted merge of the 16 waves.
+__device__ inline float sort64_asc(float x, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const float y = __shfl_xor(x, j);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+    }
+  return x;
+}
+// a, b ascending: the 64 smallest of both, ascending
+__device__ inline float merge64_asc(float a, float b, int lane) {
+  float x = fminf(a, __shfl(b, 63 - lane));   // bitonic sequence holding the 64 smallest
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) {
+    const float y = __shfl_xor(x, j);
+    x = (lane & j) == 0 ? fminf(x, y) : fmaxf(x, y);
+  }
+  return x;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__restrict__ codes, int ng, int m_pad,
+                                                             const float4 *__restrict__ tables, int row_from,
+                                                             int row_until, int rb_begin, int e_count, RbMap mp, int B,
+                                                             int keff, float *__restrict__ tau0,
+                                                             float *__restrict__ fin_v, int *__restrict__ fin_i) {
+  constexpr int NW = FILTER_THREADS / 64;
+  using Word = typename CodeWord<VEC>::type;
+  extern __shared__ uint4 qlds[];
+  float4 *lds = reinterpret_cast<float4 *>(qlds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qg4 = blockIdx.x;
+  {
+    const int n16 = m_pad * 256;
+    const float4 *src = tables + (size_t)qg4 * n16;
+    for (int e = tid; e < n16; e += FILTER_THREADS) lds[e] = src[e];
+  }
+  __syncthreads();
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  int mp_p = wave / mp.width, mp_r = wave - mp_p * mp.width;
+  auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
+  auto advance = [&](int &p, int &r) { r += NW; while (r >= mp.width) { r -= mp.width; p++; } };
+  float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  Word w_first{};
+  if (wave < e_count) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+  for (int e = wave; e < e_count; e += NW) {
+    const int rb = block_of(mp_p, mp_r);
+    advance(mp_p, mp_r);
+    const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
+    Word w = w_first;
+    if (e + NW < e_count) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};     // the reference's order: j ascending, unfused fp32
+    for (int g = 0; g < ng; g++) {
+      Word wn = w;
+      if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
+      const float4 *tj = lds + g * VEC * 256;
+#pragma unroll
+      for (int b = 0; b < VEC; b++) {
+        const float4 t = tj[b * 256 + code_byte<VEC>(w, b)];
+        acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+      }
+      w = wn;
+    }
+    const int row = rb * 64 + lane;
+    if (row >= row_from && row < row_until) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) mn[u] = fminf(mn[u], acc[u]);   // NaN distances are ignored
+    }
+  }
+  __syncthreads();                     // the table is dead: reuse LDS for the per-wave sorted minima
+  float *sv = reinterpret_cast<float *>(qlds);
+#pragma unroll
+  for (int u = 0; u < 4; u++) sv[(u * NW + wave) * 64 + lane] = sort64_asc(mn[u], lane);
+  __syncthreads();
+  if (wave < 4) {
+    const int u = wave, q = qg4 * 4 + u;
+    float best = sv[(u * NW) * 64 + lane];
+    for (int w2 = 1; w2 < NW; w2++) best = merge64_asc(best, sv[(u * NW + w2) * 64 + lane], lane);
+    if (q < B) {
+      if (lane == keff - 1) tau0[q] = best;          // +inf when fewer than K+1 groups saw a row
+      if (lane < keff) { fin_v[(size_t)q * keff + lane] = INFINITY; fin_i[(size_t)q * keff + lane] = INT_MAX; }
+    }
+  }
+}
+
 // ---- the filter: lane = row, 16*NQG queries per workgroup, NADD entries summed per byte -------
 template <int NQG, int VEC, int NADD>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const uint4 *__restrict__ qtab, int row_from, int row_until,
-    int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap) {
+    int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue,
+    int cap /* entries per sub-queue */) {
   constexpr int NW = FILTER_THREADS / 64;
   constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
   using Word = typename CodeWord<VEC>::type;
@@ -136,6 +235,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, chunk = blockIdx.y;
   const int tab = m_pad * 256;   // uint4 entries per 16-query group
+  const int slot = chunk & (NSLOT - 1);   // spreads the queue-tail atomics of one query over NSLOT counters
   {
     const int n16 = NQG * tab;
     const uint4 *src = qtab + (size_t)tile * n16;
@@ -215,12 +315,14 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
           if (__ballot(l != 0) == 0ull) continue;
           const int q0 = (tile * NQG + s) * 16 + 4 * (x >> 1) + (x & 1);
           if (l & 0xFFFFu) {
-            const int pos = atomicAdd(&cnt[q0], 1);
-            if (pos < cap) queue[(size_t)q0 * cap + pos] = row;
+            const int sq = q0 * NSLOT + slot;
+            const int pos = atomicAdd(&cnt[sq], 1);
+            if (pos < cap) queue[(size_t)sq * cap + pos] = row;
           }
           if (l >> 16) {
-            const int pos = atomicAdd(&cnt[q0 + 2], 1);
-            if (pos < cap) queue[(size_t)(q0 + 2) * cap + pos] = row;
+            const int sq = (q0 + 2) * NSLOT + slot;
+            const int pos = atomicAdd(&cnt[sq], 1);
+            if (pos < cap) queue[(size_t)sq * cap + pos] = row;
           }
         }
     }
@@ -236,15 +338,34 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
                                                        int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt) {
   using Word = typename CodeWord<VEC>::type;
   const int q = blockIdx.x, lane = threadIdx.x;
-  if (q >= B) {
-    if (lane == 0) cnt[q] = 0;
-    return;
+  // sub-queue fill levels -> exclusive offsets of a flat numbering of this query's survivors
+  int mine = lane < NSLOT ? cnt[q * NSLOT + lane] : 0;
+  if (lane < NSLOT) cnt[q * NSLOT + lane] = 0;
+  if (q >= B) return;
+  if (__ballot(mine > cap) != 0ull) {
+    if (lane == 0) fb_tile[q / qt] = 1;   // a sub-queue overflowed: the exact scan redoes this query tile
+    mine = min(mine, cap);
   }
-  int n = cnt[q];
-  if (n > cap) {
-    if (lane == 0) fb_tile[q / qt] = 1;   // queue overflow: the exact scan redoes this query tile
-    n = cap;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < NSLOT; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
   }
+  const int n = readlane_i(incl, NSLOT - 1);
+  int start[NSLOT];
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; sl++) start[sl] = readlane_i(incl - mine, sl);
+  auto entry = [&](int e) {   // e-th survivor of the query, e < n
+    int sl = 0;
+#pragma unroll
+    for (int x = 1; x < NSLOT; x++) sl += e >= start[x];
+    int off = start[0];
+#pragma unroll
+    for (int x = 1; x < NSLOT; x++) off = sl == x ? start[x] : off;
+    return queue[((size_t)q * NSLOT + sl) * cap + (e - off)];
+  };
+
   WaveList wl;
   wl.v = lane < keff ? fin_v[(size_t)q * keff + lane] : INFINITY;
   wl.i = lane < keff ? fin_i[(size_t)q * keff + lane] : INT_MAX;
@@ -253,14 +374,20 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
   // W = 4 interleaved fp32 tables: entry (j, c) of query q at ((q/4 * m_pad + j) * 256 + c) * 4 + q%4
   const float *tq = tables + (size_t)(q >> 2) * m_pad * 1024 + (q & 3);
   const Word *cw = reinterpret_cast<const Word *>(codes);
-  const int *qq = queue + (size_t)q * cap;
+  // two-deep software pipeline: row ids two batches ahead, first code word one batch ahead
+  int row_n = lane < n ? entry(lane) : 0;
+  Word w_n = cw[((size_t)(row_n >> 6) * ng) * 64 + (row_n & 63)];
+  int row_nn = 64 + lane < n ? entry(64 + lane) : 0;
   for (int base = 0; base < n; base += 64) {
-    const int e = base + lane;
-    const bool have = e < n;
-    const int row = have ? qq[e] : 0;
+    const bool have = base + lane < n;
+    const int row = row_n;
+    const Word w0 = w_n;
+    row_n = row_nn;
+    w_n = cw[((size_t)(row_n >> 6) * ng) * 64 + (row_n & 63)];
+    row_nn = base + 128 + lane < n ? entry(base + 128 + lane) : 0;
     float d = 0.f;                      // the reference's order: j ascending, unfused fp32
     for (int g = 0; g < ng; g++) {
-      const Word w = cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
+      const Word w = g == 0 ? w0 : cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
       float t[VEC];
 #pragma unroll
       for (int b = 0; b < VEC; b++) t[b] = tq[((size_t)(g * VEC + b) * 256 + code_byte<VEC>(w, b)) * 4];
@@ -281,7 +408,6 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
     fin_v[(size_t)q * keff + lane] = wl.v;
     fin_i[(size_t)q * keff + lane] = wl.i;
   }
-  if (lane == 0) cnt[q] = 0;
 }
 
 template <int NQG, int VEC, int NADD>
@@ -332,16 +458,18 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   const int qmax = 255 / nadd;
   const int ftiles = ceil_div(B, 16 * nqg);
   const int Bq = ftiles * nqg * 16;
-  const int cap = t.filter_cap;
+  const int cap = std::max(64, t.filter_cap / NSLOT);   // entries per sub-queue
   const int rb_begin = from / 64;
   const int rb_total = ceil_div(until, 64) - rb_begin;
   const int P = t.filter_period;
-  const int s1 = std::min(t.filter_stage1, P - 2);
-  const RbMap sample{P, 0, 1}, stage1{P, 1, s1}, stage2{P, 1 + s1, P - 1 - s1}, all{1, 0, 1};
+  const int s0 = std::min(std::max(t.filter_stage0, 0), P - 2);
+  const int s1 = std::min(std::max(t.filter_stage1, 1), P - 1 - s0);
+  const RbMap all{1, 0, 1};
+  const RbMap stages[3] = {{P, 0, s0}, {P, s0, s1}, {P, s0 + s1, P - s0 - s1}};
   const int NW = t.threads / 64;
 
-  auto chunking = [&](int e_count, int tiles, int &nchunks, int &per) {
-    int want = ceil_div(t.target_blocks, tiles);
+  auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
+    int want = ceil_div(target, tiles);
     int maxc = e_count / (2 * NW);
     if (maxc < 1) maxc = 1;
     nchunks = want < maxc ? want : maxc;
@@ -349,47 +477,59 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     nchunks = ceil_div(e_count, per);
   };
 
-  // stage 0: exact scan of the sample blocks -> running (K+1)-lists
-  int e0n = rbmap_count(rb_total, sample), c0 = 1, p0 = 1;
-  chunking(e0n, ntiles, c0, p0);
   const int cfb = std::max(1, ceil_div(256, ntiles));   // fallback: one workgroup per CU when everything is redone
   const int pfb = ceil_div(rb_total, cfb);
   const int cfb_n = ceil_div(rb_total, pfb);
-  const int cmax = std::max(c0, cfb_n);
   ix->tables.ensure((size_t)Bp * ix->m_pad * 256);
-  ix->part_v.ensure((size_t)Bp * cmax * keff);
-  ix->part_i.ensure((size_t)Bp * cmax * keff);
+  ix->part_v.ensure((size_t)Bp * cfb_n * keff);
+  ix->part_i.ensure((size_t)Bp * cfb_n * keff);
   ix->gtau.ensure((size_t)Bp);
   ix->fin_v.ensure((size_t)Bq * keff);
   ix->fin_i.ensure((size_t)Bq * keff);
   ix->qmins.ensure((size_t)Bq * ix->m_pad);
   ix->qtab.ensure((size_t)(Bq / 16) * ix->m_pad * 256 * 16);
-  ix->sv_cnt.ensure((size_t)Bq);
-  ix->sv_queue.ensure((size_t)Bq * cap);
+  ix->sv_cnt.ensure((size_t)Bq * NSLOT);
+  ix->sv_queue.ensure((size_t)Bq * NSLOT * cap);
   ix->fb_tile.ensure((size_t)ntiles);
+  ix->tau0.ensure((size_t)Bp);
   HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
   HIP_CHECK(hipMemsetAsync(ix->fb_tile.p, 0, sizeof(int) * (size_t)ntiles, st));
-  HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Bq, st));
+  HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Bq * NSLOT, st));
 
   launch_build_tables(4, ix, dQ, B, Bp, ix->tables.p, st);
-  launch_scan(ix, ntiles, c0, rb_begin, e0n, p0, sample, from, until, keff, st);
-  launch_merge(false, ix->part_v.p, ix->part_i.p, c0, (long long)keff, (long long)c0 * keff, B, K, nullptr, nullptr,
-               nullptr, nullptr, ix->fin_v.p, ix->fin_i.p, st);
+  {   // bounds from a strided sample of about filter_sample rows; resets the running lists
+    int sblocks = std::max(NW, std::min(rb_total, ceil_div(t.filter_sample, 64)));
+    const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
+    const int se = rbmap_count(rb_total, smap);
+    const size_t lds_bytes = std::max((size_t)ix->m_pad * 256 * 16, (size_t)4 * NW * 64 * 4);
+#define BS(V)                                                                                                       \
+    {                                                                                                               \
+      auto kern = bound_scan<V>;                                                                                    \
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                   \
+      hipLaunchKernelGGL(kern, dim3(Bp / 4), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,   \
+                         reinterpret_cast<const float4 *>(ix->tables.p), from, until, rb_begin, se, smap, B, keff,  \
+                         ix->tau0.p, ix->fin_v.p, ix->fin_i.p);                                                     \
+    }
+    if (ix->vec == 16) BS(16) else BS(4)
+#undef BS
+    HIP_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(qt_mins, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
                      reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, ix->qmins.p);
   HIP_CHECK(hipGetLastError());
 
   const bool stats = getenv("GULON_FILTER_STATS") != nullptr;
-  const RbMap stages[2] = {stage1, stage2};
-  for (int sidx = 0; sidx < 2; sidx++) {
+  for (int sidx = 0; sidx < 3; sidx++) {
     const RbMap mp = stages[sidx];
     const int en = rbmap_count(rb_total, mp);
     if (en <= 0) continue;
     int nc = 1, per = 1;
-    chunking(en, ftiles, nc, per);
+    chunking(en, ftiles, t.filter_blocks, nc, per);
     hipLaunchKernelGGL(qt_quantize, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
                        reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, B, ix->qmins.p,
-                       ix->fin_v.p, ix->fin_i.p, keff, qmax, reinterpret_cast<uint4 *>(ix->qtab.p), ix->fb_tile.p, QT);
+                       ix->fin_v.p, ix->fin_i.p, ix->tau0.p, keff, qmax, reinterpret_cast<uint4 *>(ix->qtab.p),
+                       ix->fb_tile.p, QT);
     HIP_CHECK(hipGetLastError());
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ix->profile) {
@@ -400,12 +540,12 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, st);
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
       HIP_CHECK(hipStreamSynchronize(st));
-      std::vector<int> h((size_t)Bq);
+      std::vector<int> h((size_t)Bq * NSLOT);
       HIP_CHECK(hipMemcpy(h.data(), ix->sv_cnt.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
       long long tot = 0; int mx = 0;
       for (int v : h) { tot += v; mx = std::max(mx, v); }
       fprintf(stderr, "[filter] stage %d: %d row blocks, %d x %d workgroups, survivors total %lld (%.3g of pairs), "
-              "max per query %d (cap %d)\n", sidx + 1, en, ftiles, nc, tot, (double)tot / ((double)en * 64 * B), mx, cap);
+              "max per sub-queue %d (cap %d)\n", sidx + 1, en, ftiles, nc, tot, (double)tot / ((double)en * 64 * B), mx, cap);
     }
     if (ix->profile) {
       HIP_CHECK(hipEventRecord(ev1, st));

@@ -478,7 +478,7 @@ void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpa
 ScanTuning::ScanTuning() {
   static const char *keys[] = {"GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE", "GULON_SCAN_PRUNE_FROM", "GULON_SCAN_FILTER",
                                "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
-                               "GULON_FILTER_NADD"};
+                               "GULON_FILTER_NADD", "GULON_FILTER_SAMPLE", "GULON_FILTER_STAGE0", "GULON_FILTER_BLOCKS"};
   for (const char *k : keys)
     if (const char *e = getenv(k)) set(k, atoi(e));
 }
@@ -494,6 +494,9 @@ bool ScanTuning::set(const char *key, int v) {
   else if (k == "GULON_FILTER_STAGE1") { if (v >= 1) filter_stage1 = v; }
   else if (k == "GULON_FILTER_CAP") { if (v >= 64) filter_cap = v; }
   else if (k == "GULON_FILTER_NADD") { if (v == 2 || v == 4) filter_nadd = v; }
+  else if (k == "GULON_FILTER_SAMPLE") { if (v >= 1) filter_sample = v; }
+  else if (k == "GULON_FILTER_STAGE0") { if (v >= 0) filter_stage0 = v; }
+  else if (k == "GULON_FILTER_BLOCKS") { if (v >= 1) filter_blocks = v; }
   else return false;
   return true;
 }

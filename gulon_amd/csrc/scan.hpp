@@ -46,7 +46,7 @@ struct gulon_index {
   DevBuf<int> rp_list, rp_count, rp_segcnt, rp_evcnt, rp_overflow, rp_evi, rp_precnt;
   DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv;
   // quantized lower-bound filter (filter.hip)
-  DevBuf<float> fin_v, qmins;       // running exact (K+1)-lists [Bq][keff]; per (query, quantizer) table minima
+  DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
   DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;
   DevBuf<uint8_t> qtab;             // [Bq/16][m_pad][256][16] quantized table entries
   // optional hipEvent bracketing of the dominant scan kernel (bench.py roofline line)
@@ -79,9 +79,12 @@ struct ScanTuning {
   int filter = 1;            // quantized lower-bound filter on/off
   int filter_min_rb = 8192;  // smallest range (in 64-row blocks) the filter is used for
   int filter_period = 128;   // row blocks per sampling period
-  int filter_stage1 = 12;    // blocks per period scanned by the first (loose) filter stage
+  int filter_sample = 32768; // sample rows whose exact distances give the initial bounds
+  int filter_stage0 = 0;     // blocks per period scanned by an extra first filter stage (0: none)
+  int filter_stage1 = 12;    // blocks per period scanned by the second filter stage
   int filter_cap = 32768;    // survivor queue entries per query and stage
   int filter_nadd = 2;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels)
+  int filter_blocks = 4096;         // workgroups aimed for by a filter launch
   ScanTuning();
   bool set(const char *key, int v);
 };

@@ -3,7 +3,7 @@
 The filter only changes how much work is done, never a result: everything here must equal the
 CPU oracle bit for bit, exactly as the unfiltered scan does.  The filter is normally reserved for
 large row ranges; the tuning knobs shrink its thresholds so that small, oracle-sized cases run
-through every stage (sample scan, two filter stages, survivor re-evaluation, fallback)."""
+through every stage (sample bounds, three filter stages, survivor re-evaluation, fallback)."""
 import numpy as np
 import pytest
 
@@ -13,7 +13,8 @@ from test_gpu_query import _check, _make
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_MIN_RB": 8192, "GULON_FILTER_PERIOD": 128,
-            "GULON_FILTER_STAGE1": 12, "GULON_FILTER_CAP": 32768, "GULON_FILTER_NADD": 2}
+            "GULON_FILTER_STAGE0": 2, "GULON_FILTER_STAGE1": 12, "GULON_FILTER_CAP": 32768,
+            "GULON_FILTER_NADD": 2, "GULON_FILTER_SAMPLE": 4096}
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +31,8 @@ def tune(g):
     def set_(**kw):
         for k, v in kw.items():
             N.check(N.lib().gulon_scan_tuning(k.encode(), int(v)))
-    set_(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE1=2)
+    set_(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE0=1, GULON_FILTER_STAGE1=2,
+         GULON_FILTER_SAMPLE=512)
     yield set_
     set_(**DEFAULTS)
 
@@ -112,9 +114,10 @@ def test_ties_are_flagged_and_replayed(oracle, g, tune):
 
 
 def test_queue_overflow_falls_back_to_exact_scan(oracle, g, tune):
-    """A 64-entry survivor queue overflows for every query; the device-side fallback redoes them."""
+    """64-entry survivor sub-queues (1024 per query) overflow for every query; the device-side
+    fallback redoes them with the exact scan."""
     tune(GULON_FILTER_CAP=64)
-    n, d, m, k, B, K = 80000, 32, 8, 16, 21, 10          # few centroids: coarse distances, many survivors
+    n, d, m, k, B, K = 80000, 16, 4, 2, 21, 10           # 16 distinct codes: ~5000 rows per distance value
     cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=9)
     Q = np.random.default_rng(4).standard_normal((B, d)).astype(np.float32)
     ix = g.PQIndex(pq, enc)
