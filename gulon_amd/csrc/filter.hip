@@ -533,8 +533,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     HIP_CHECK(hipGetLastError());
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ix->profile) {
-      HIP_CHECK(hipEventCreate(&ev0));
-      HIP_CHECK(hipEventCreate(&ev1));
+      ev0 = ix->take_event();
+      ev1 = ix->take_event();
       HIP_CHECK(hipEventRecord(ev0, st));
     }
     launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, st);

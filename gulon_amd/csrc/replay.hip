@@ -10,20 +10,26 @@
 //   an insertion happens at row r  <=>  fewer than K rows came before, or
 //                                       dist(r) < K-th smallest distance among rows < r
 //
-// which depends only on the multiset of earlier distances, not on the heap's shape.  Hence
-//   1. rp_seg_scan<0>: every segment of rows computes its K smallest distances        (parallel)
-//   2. rp_prefix:      exclusive prefix-merge over segments -> K smallest before each segment
-//   3. rp_seg_scan<1>: every segment replays its rows in order against that prefix and
-//                      emits its events (row, distance)                                  (parallel)
-//   4. rp_heap:        one thread per query pushes the ~K ln(n/K) events, in row order,
-//                      through a literal TopKHeap and drains it like Result.fromHeap.
+// and the literal heap makes exactly that test itself.  So it is enough to feed it, in row
+// order, any SUPERSET of the inserting rows: a row that would not insert is rejected by the
+// heap exactly as in the reference and leaves it untouched.  A superset is cheap to produce in
+// parallel: a segment of rows that starts from an upper bound of the true running threshold
+// (the K smallest distances of some earlier rows) and tightens it with its own rows emits every
+// row below its running threshold -- all true insertions and a few more.  Three levels:
+//   level 0  rows [0, 4096)            one wave, cold start (exact events)
+//   level 1  the next 128 K rows       32 segments, each starting from level 0's K smallest
+//   level 2  the rest                  up to 2048 segments starting from the K smallest of levels 0+1
+// (about K * (ln(4096/K) + 1 + 1 + n/132K) candidates per query), then
+//   rp_heap  sorts the candidates by row id and pushes them through a literal TopKHeap,
+//            drained like Result.fromHeap.
 // Distances are the same bit-exact j-ordered sums as in the main scan.
 #include "scan.hpp"
 
 namespace gulon {
 
-constexpr int RP_MAXF = 1024;   // flagged queries replayed per batch (all of a 1024-query batch)
-constexpr int RP_MAXSEG = 512;
+constexpr int RP_MAXF = 1024;    // flagged queries replayed per batch (all of a 1024-query batch)
+constexpr int RP_POOL = 8192;    // candidate rows kept per flagged query (more: the flagged result stays)
+constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = 2048, RP_L1_SEG = 64, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
 
 __global__ void rp_collect(const int *__restrict__ flags, int B, int maxf, int *__restrict__ list,
                            int *__restrict__ count) {
@@ -52,174 +58,225 @@ __device__ inline uint32_t rp_byte(const uint4 &w, int b) {
   return (x >> (8 * (b & 3))) & 0xFFu;
 }
 
-// One wave per (segment, flagged query).  PHASE 0: K smallest distances of the segment.
-// PHASE 1: events of the segment given the K smallest distances of all earlier rows.
-template <int VEC, int PHASE>
-__global__ __launch_bounds__(64) void rp_seg_scan(const uint8_t *__restrict__ codes, int ng, int m_pad,
-                                                  const float *__restrict__ tables /*[f][m_pad][256]*/,
-                                                  const int *__restrict__ count, int maxf, int row_from, int row_until,
-                                                  int row_base, int rb_begin, int rb_end, int rb_per_seg, int nseg,
-                                                  int K, float *__restrict__ segtop, int *__restrict__ segcnt,
-                                                  const float *__restrict__ prefix, const int *__restrict__ precnt,
-                                                  int evcap, float *__restrict__ evv, int *__restrict__ evi,
-                                                  int *__restrict__ evcnt, int *__restrict__ overflow) {
+// One wave per (segment, flagged query); 4 segments per workgroup share the query's table in LDS.
+// Starts from the K smallest distances of earlier rows (start_v, ascending; nullptr: cold) and
+// emits every row below its running K-th smallest distance into the query's candidate pool.
+template <int VEC>
+__global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes, int ng, int m_pad,
+                                               const float *__restrict__ tables /*[f][m_pad][256]*/,
+                                               const int *__restrict__ count, int maxf, int row_from, int row_until,
+                                               int row_base, int rb_lo, int rb_hi, int rb_per_seg, int nseg, int K,
+                                               const float *__restrict__ start_v, const int *__restrict__ start_c,
+                                               float *__restrict__ out_v, int *__restrict__ out_i,
+                                               int *__restrict__ out_c, float *__restrict__ evv,
+                                               int *__restrict__ evi, int *__restrict__ evcnt) {
   using Word = typename RpWord<VEC>::type;
   extern __shared__ float tab[];   // m_pad * 256
-  const int s = blockIdx.x, lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x * 4 + wave;
   const int nf = min(*count, maxf);
   // the grid has a fixed, small y extent; each block walks the flagged queries f = y, y+Y, ...
-  // (an empty launch then costs a few thousand blocks instead of nseg * maxf)
   for (int f = blockIdx.y; f < nf; f += gridDim.y) {
-  __syncthreads();
-  {
-    const float *src = tables + (size_t)f * m_pad * 256;
-    for (int e = lane; e < m_pad * 256; e += 64) tab[e] = src[e];
-  }
-  __syncthreads();
-  const size_t fs = (size_t)f * nseg + s;
-  WaveList wl;
-  wl.init();
-  int cnt = 0;
-  if (PHASE == 1) {
-    cnt = precnt[fs];
-    if (lane < cnt) { wl.v = prefix[fs * K + lane]; wl.i = -1; }   // earlier rows: sort before any tie
-    if (cnt >= K) { wl.tau = readlane_f(wl.v, K - 1); wl.tau_i = -1; }
-  }
-  int nev = 0;
-  const Word *cw = reinterpret_cast<const Word *>(codes);
-  const int rb0 = rb_begin + s * rb_per_seg;
-  const int rb1 = min(rb_end, rb0 + rb_per_seg);
-  // one wave walks the segment alone: keep the next row block's first code word in flight
-  Word w_first{};
-  if (rb0 < rb1) w_first = cw[((size_t)rb0 * ng) * 64 + lane];
-  for (int rb = rb0; rb < rb1; rb++) {
-    float acc = 0.f;
-    Word w0 = w_first;
-    if (rb + 1 < rb1) w_first = cw[((size_t)(rb + 1) * ng) * 64 + lane];
-    for (int g = 0; g < ng; g++) {
-      Word w = g == 0 ? w0 : cw[((size_t)rb * ng + g) * 64 + lane];
-      const float *tj = tab + g * VEC * 256;
-#pragma unroll
-      for (int b = 0; b < VEC; b++) acc += tj[b * 256 + rp_byte(w, b)];
+    __syncthreads();
+    {
+      const float *src = tables + (size_t)f * m_pad * 256;
+      for (int e = tid; e < m_pad * 256; e += 256) tab[e] = src[e];
     }
-    const int row = rb * 64 + lane;
-    const bool valid = row >= row_from && row < row_until;
-    unsigned long long mk = __ballot(valid && (cnt < K || acc < wl.tau));
-    while (mk) {
-      int l = __ffsll((long long)mk) - 1;
-      mk &= mk - 1;
-      float cv = readlane_f(acc, l);
-      int cr = rb * 64 + l + row_base;
-      if (cnt < K || cv < wl.tau) {   // TopKHeap.update: not full, or root > v (strict)
-        if (PHASE == 1) {
-          if (nev < evcap) {
-            if (lane == 0) { evv[fs * evcap + nev] = cv; evi[fs * evcap + nev] = cr; }
-          } else if (lane == 0) {
-            overflow[f] = 1;
-          }
-          nev++;
+    __syncthreads();
+    if (s >= nseg) continue;
+    WaveList wl;
+    wl.init();
+    int cnt = 0;
+    if (start_v) {
+      cnt = start_c[f];
+      if (lane < cnt) { wl.v = start_v[(size_t)f * K + lane]; wl.i = -1; }   // earlier rows: sort before any tie
+      if (cnt >= K) { wl.tau = readlane_f(wl.v, K - 1); wl.tau_i = -1; }
+    }
+    // pending candidates of this wave: lane j holds the j-th; flushed with one atomic per 64
+    float pv = 0.f;
+    int pi = 0, npend = 0;
+    auto flush = [&]() {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&evcnt[f], npend);
+      base = readlane_i(base, 0);
+      if (lane < npend && base + lane < RP_POOL) {
+        evv[(size_t)f * RP_POOL + base + lane] = pv;
+        evi[(size_t)f * RP_POOL + base + lane] = pi;
+      }
+      npend = 0;
+    };
+    const Word *cw = reinterpret_cast<const Word *>(codes);
+    const int rb0 = rb_lo + s * rb_per_seg;
+    const int rb1 = min(rb_hi, rb0 + rb_per_seg);
+    Word w_first{};
+    if (rb0 < rb1) w_first = cw[((size_t)rb0 * ng) * 64 + lane];
+    for (int rb = rb0; rb < rb1; rb++) {
+      float acc = 0.f;
+      Word w0 = w_first;
+      if (rb + 1 < rb1) w_first = cw[((size_t)(rb + 1) * ng) * 64 + lane];
+      for (int g = 0; g < ng; g++) {
+        Word w = g == 0 ? w0 : cw[((size_t)rb * ng + g) * 64 + lane];
+        const float *tj = tab + g * VEC * 256;
+#pragma unroll
+        for (int b = 0; b < VEC; b++) acc += tj[b * 256 + rp_byte(w, b)];
+      }
+      const int row = rb * 64 + lane;
+      const bool valid = row >= row_from && row < row_until;
+      unsigned long long mk = __ballot(valid && (cnt < K || acc < wl.tau));
+      while (mk) {
+        int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        float cv = readlane_f(acc, l);
+        int cr = rb * 64 + l + row_base;
+        if (cnt < K || cv < wl.tau) {   // TopKHeap.update: not full, or root > v (strict)
+          if (lane == npend) { pv = cv; pi = cr; }
+          if (++npend == 64) flush();
+          wl.insert(cv, cr, K, lane);
+          if (cnt < K) cnt++;
         }
-        wl.insert(cv, cr, K, lane);
-        if (cnt < K) cnt++;
       }
     }
-  }
-  if (PHASE == 0) {
-    if (lane < K) segtop[fs * K + lane] = wl.v;
-    if (lane == 0) segcnt[fs] = cnt;
-  } else if (lane == 0) {
-    evcnt[fs] = min(nev, evcap);
-  }
+    if (npend) flush();
+    if (out_v) {
+      const size_t fs = (size_t)f * nseg + s;
+      if (lane < K) { out_v[fs * K + lane] = wl.v; out_i[fs * K + lane] = wl.i; }
+      if (lane == 0) out_c[fs] = cnt;
+    }
   }
 }
 
-// exclusive prefix over segments of "the K smallest distances so far"; one wave per query.
-// Segment s+1's list is prefetched (one coalesced load, lane e = entry e) while s is merged.
-__global__ __launch_bounds__(64) void rp_prefix(const float *__restrict__ segtop, const int *__restrict__ segcnt,
-                                                const int *__restrict__ count, int maxf, int nseg, int K,
-                                                float *__restrict__ prefix, int *__restrict__ precnt) {
+// K smallest distances of (start list) + (the new entries of nseg segment lists); one wave per query.
+__global__ __launch_bounds__(64) void rp_merge(const float *__restrict__ start_v, const int *__restrict__ start_c,
+                                               const float *__restrict__ seg_v, const int *__restrict__ seg_i,
+                                               const int *__restrict__ count, int maxf, int nseg, int K,
+                                               float *__restrict__ out_v, int *__restrict__ out_c) {
   const int lane = threadIdx.x;
   const int nf = min(*count, maxf);
   for (int f = blockIdx.x; f < nf; f += gridDim.x) {
     WaveList wl;
     wl.init();
-    int cnt = 0;
-    const size_t f0 = (size_t)f * nseg;
-    float nxt_v = lane < K ? segtop[f0 * K + lane] : INFINITY;
-    int nxt_c = segcnt[f0];
+    int cnt = start_c[f];
+    if (lane < cnt) { wl.v = start_v[(size_t)f * K + lane]; wl.i = -1; }
+    if (cnt >= K) { wl.tau = readlane_f(wl.v, K - 1); wl.tau_i = -1; }
     for (int s = 0; s < nseg; s++) {
-      const size_t fs = f0 + s;
-      const float cur_v = nxt_v;
-      const int sc = nxt_c;
-      if (s + 1 < nseg) {
-        nxt_v = lane < K ? segtop[(fs + 1) * K + lane] : INFINITY;
-        nxt_c = segcnt[fs + 1];
-      }
-      if (lane < K) prefix[fs * K + lane] = wl.v;
-      if (lane == 0) precnt[fs] = cnt;
-      for (int e = 0; e < sc; e++) {
-        float cv = readlane_f(cur_v, e);
+      const size_t fs = (size_t)f * nseg + s;
+      const float cur_v = lane < K ? seg_v[fs * K + lane] : INFINITY;
+      const int cur_i = lane < K ? seg_i[fs * K + lane] : INT_MAX;
+      for (int e = 0; e < K; e++) {
+        const float cv = readlane_f(cur_v, e);
+        const int ci = readlane_i(cur_i, e);
+        if (ci == INT_MAX) break;          // padding: the list is shorter than K
+        if (ci == -1) continue;            // inherited from the start list
         if (cnt < K || cv < wl.tau) {
           wl.insert(cv, s * 64 + e, K, lane);
           if (cnt < K) cnt++;
         } else {
-          break;   // segtop is ascending: nothing smaller follows
+          break;                           // ascending: nothing smaller follows
         }
       }
     }
+    if (lane < K) out_v[(size_t)f * K + lane] = wl.v;
+    if (lane == 0) out_c[f] = cnt;
   }
 }
 
-// literal TopKHeap (TopKHeap.scala) over the events, then Result.fromHeap (Index.scala:83-94).
-// One wave per flagged query: the lanes first pack the per-segment event lists into one
-// contiguous LDS array (wave prefix sum over the segment counts), then lane 0 runs the heap.
-constexpr int RP_LDS_EVENTS = 4096;
-__global__ __launch_bounds__(64) void rp_heap(const float *__restrict__ evv, const int *__restrict__ evi,
-                                              const int *__restrict__ evcnt, const int *__restrict__ overflow,
-                                              const int *__restrict__ list, const int *__restrict__ count, int maxf,
-                                              int nseg, int evcap, int K, int *__restrict__ out_idx,
-                                              float *__restrict__ out_dist, int *__restrict__ out_count,
-                                              int *__restrict__ out_flags) {
-  __shared__ float sv[RP_LDS_EVENTS];
-  __shared__ int si[RP_LDS_EVENTS];
-  __shared__ int hk[GULON_MAX_K + 1];
-  __shared__ float hv[GULON_MAX_K + 1];
-  const int lane = threadIdx.x;
+// literal TopKHeap (TopKHeap.scala) over the candidates in row order, then Result.fromHeap
+// (Index.scala:83-94).  One workgroup per flagged query:
+//   1. the candidate pool is sorted by row id (bitonic, LDS);
+//   2. wave 0 walks it with a running K-smallest list and keeps only the rows that really
+//      insert (distance below the K-th smallest so far) -- the rest would be rejected by the heap;
+//   3. wave 0 pushes those through the heap (kept in registers, lane = slot) and drains it.
+constexpr int RP_KEEP = 2048;
+__global__ __launch_bounds__(256) void rp_heap(const float *__restrict__ evv, const int *__restrict__ evi,
+                                               const int *__restrict__ evcnt, const int *__restrict__ list,
+                                               const int *__restrict__ count, int maxf, int K,
+                                               int *__restrict__ out_idx, float *__restrict__ out_dist,
+                                               int *__restrict__ out_count, int *__restrict__ out_flags,
+                                               unsigned long long *__restrict__ dbg) {
+  extern __shared__ float rp_lds[];
+  float *cv = rp_lds;                                         // [RP_POOL] candidate distances
+  int *ci = reinterpret_cast<int *>(rp_lds + RP_POOL);        // [RP_POOL] candidate rows
+  float *sv = rp_lds + 2 * RP_POOL;                           // [RP_KEEP] inserting rows, in row order
+  int *si = reinterpret_cast<int *>(rp_lds + 2 * RP_POOL + RP_KEEP);
+  __shared__ int nkeep;
+  const int tid = threadIdx.x;
   const int nf = min(*count, maxf);
   for (int f = blockIdx.x; f < nf; f += gridDim.x) {
     __syncthreads();
-    if (overflow[f]) continue;   // keeps the (distance, row id) result and its tie flags
-    // pack events: segment order = row order
-    int total = 0;
-    for (int s0 = 0; s0 < nseg; s0 += 64) {
-      const int s = s0 + lane;
-      const size_t fs = (size_t)f * nseg + s;
-      const int c = s < nseg ? evcnt[fs] : 0;
-      int inc = c;
-      for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-      }
-      const int base = total + inc - c;
-      for (int e = 0; e < c; e++) {
-        if (base + e < RP_LDS_EVENTS) { sv[base + e] = evv[fs * evcap + e]; si[base + e] = evi[fs * evcap + e]; }
-      }
-      total += __shfl(inc, 63);
+    const int total = evcnt[f];
+    if (total > RP_POOL) continue;   // too many candidates: keeps the (distance, row id) result and its tie flags
+    if (dbg && tid == 0 && f == 0) dbg[0] = wall_clock64();
+    int n2 = 64;
+    while (n2 < total) n2 <<= 1;
+    for (int e = tid; e < n2; e += 256) {
+      ci[e] = e < total ? evi[(size_t)f * RP_POOL + e] : INT_MAX;
+      cv[e] = e < total ? evv[(size_t)f * RP_POOL + e] : INFINITY;
     }
     __syncthreads();
-    if (total > RP_LDS_EVENTS) continue;   // too many events for the LDS staging: leave the flagged result
-    if (lane == 0) {
+    if (dbg && tid == 0 && f == 0) dbg[1] = wall_clock64();
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j >= 1; j >>= 1) {
+        for (int i = tid; i < n2; i += 256) {
+          const int l = i ^ j;
+          if (l > i) {
+            const int a = ci[i], b = ci[l];
+            if ((a > b) == ((i & k) == 0)) {
+              const float fa = cv[i], fb = cv[l];
+              ci[i] = b; ci[l] = a; cv[i] = fb; cv[l] = fa;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    if (dbg && tid == 0 && f == 0) dbg[2] = wall_clock64();
+    if (tid < 64) {
+      const int lane = tid;
+      WaveList wl;
+      wl.init();
+      int cnt = 0, nk = 0;
+      for (int base = 0; base < total; base += 64) {
+        const bool have = base + lane < total;
+        const float v = have ? cv[base + lane] : INFINITY;
+        const int r = have ? ci[base + lane] : INT_MAX;
+        unsigned long long mk = __ballot(have && (cnt < K || v < wl.tau));
+        while (mk) {
+          const int l = __ffsll((long long)mk) - 1;
+          mk &= mk - 1;
+          const float x = readlane_f(v, l);
+          const int xr = readlane_i(r, l);
+          if (cnt < K || x < wl.tau) {   // TopKHeap.update inserts: not full, or root > x (strict)
+            if (lane == 0 && nk < RP_KEEP) { sv[nk] = x; si[nk] = xr; }
+            nk++;
+            wl.insert(x, xr, K, lane);
+            if (cnt < K) cnt++;
+          }
+        }
+      }
+      if (lane == 0) nkeep = nk;
+    }
+    __syncthreads();
+    const int kept = nkeep;
+    if (dbg && tid == 0 && f == 0) dbg[5] = kept;
+    if (kept > RP_KEEP) continue;
+    if (dbg && tid == 0 && f == 0) dbg[3] = wall_clock64();
+    if (tid < 64) {
+      // the heap lives in registers: lane i = slot i (K <= 63); every index below is wave-uniform
+      const int lane = tid;
+      float hv = 0.f;
+      int hk = 0;
       int size = 0;
       auto swp = [&](int a, int b) {
-        int tk = hk[a]; float tv = hv[a];
-        hk[a] = hk[b]; hv[a] = hv[b];
-        hk[b] = tk; hv[b] = tv;
+        const float va = readlane_f(hv, a), vb = readlane_f(hv, b);
+        const int ka = readlane_i(hk, a), kb = readlane_i(hk, b);
+        if (lane == a) { hv = vb; hk = kb; }
+        if (lane == b) { hv = va; hk = ka; }
       };
       auto down = [&](int i) {                                  // percolateDown, TopKHeap.scala:30-42
         for (;;) {
-          int top = i, lc = 2 * i + 1, rc = 2 * i + 2;
-          if (lc < size && hv[top] < hv[lc]) top = lc;
-          if (rc < size && hv[top] < hv[rc]) top = rc;
+          int top = i;
+          const int lc = 2 * i + 1, rc = 2 * i + 2;
+          if (lc < size && readlane_f(hv, top) < readlane_f(hv, lc)) top = lc;
+          if (rc < size && readlane_f(hv, top) < readlane_f(hv, rc)) top = rc;
           if (top == i) break;
           swp(i, top);
           i = top;
@@ -227,35 +284,44 @@ __global__ __launch_bounds__(64) void rp_heap(const float *__restrict__ evv, con
       };
       auto del = [&]() {                                        // delete, TopKHeap.scala:57-67
         size -= 1;
-        hk[0] = hk[size];
-        hv[0] = hv[size];
+        const float lv = readlane_f(hv, size);
+        const int lk = readlane_i(hk, size);
+        if (lane == 0) { hv = lv; hk = lk; }
         down(0);
       };
-      for (int e = 0; e < total; e++) {
-        const float v = sv[e];
-        const int kk = si[e];
-        if (size == K && hv[0] > v) del();                      // update, TopKHeap.scala:69-79
-        if (size < K) {
-          hk[size] = kk;
-          hv[size] = v;
-          int i = size;
-          while (i > 0) {                                       // percolateUp, TopKHeap.scala:21-28
-            int p = (i - 1) / 2;
-            if (hv[i] > hv[p]) { swp(i, p); i = p; } else break;
+      for (int base = 0; base < kept; base += 64) {
+        const float ev = base + lane < kept ? sv[base + lane] : 0.f;
+        const int ek = base + lane < kept ? si[base + lane] : 0;
+        const int ne = min(64, kept - base);
+        for (int e = 0; e < ne; e++) {
+          const float v = readlane_f(ev, e);
+          const int kk = readlane_i(ek, e);
+          if (size == K && readlane_f(hv, 0) > v) del();        // update, TopKHeap.scala:69-79
+          if (size < K) {
+            if (lane == size) { hv = v; hk = kk; }
+            int i = size;
+            while (i > 0) {                                     // percolateUp, TopKHeap.scala:21-28
+              const int p = (i - 1) / 2;
+              if (readlane_f(hv, i) > readlane_f(hv, p)) { swp(i, p); i = p; } else break;
+            }
+            size += 1;
           }
-          size += 1;
         }
       }
       const int q = list[f];
       const int live = size;
       for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
-        out_idx[(size_t)q * K + i] = hk[0];
-        out_dist[(size_t)q * K + i] = hv[0];
+        const float tv = readlane_f(hv, 0);
+        const int tk = readlane_i(hk, 0);
+        if (lane == 0) { out_idx[(size_t)q * K + i] = tk; out_dist[(size_t)q * K + i] = tv; }
         del();
       }
-      for (int i = live; i < K; i++) { out_idx[(size_t)q * K + i] = -1; out_dist[(size_t)q * K + i] = INFINITY; }
-      if (out_count) out_count[q] = live;
-      out_flags[q] |= GULON_FLAG_EXACT_REPLAY;
+      if (lane >= live && lane < K) { out_idx[(size_t)q * K + lane] = -1; out_dist[(size_t)q * K + lane] = INFINITY; }
+      if (lane == 0) {
+        if (out_count) out_count[q] = live;
+        out_flags[q] |= GULON_FLAG_EXACT_REPLAY;
+        if (dbg && f == 0) dbg[4] = wall_clock64();
+      }
     }
   }
 }
@@ -265,44 +331,82 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
   if (B <= 0 || K <= 0 || until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
   const int maxf = std::min(B, RP_MAXF);
-  int nseg = std::min(maxf <= 64 ? RP_MAXSEG : 256, std::max(1, rb_total / 4));
-  const int gy = std::min(maxf, 16);   // y extent of the segment-scan grids
-  const int rb_per_seg = ceil_div(rb_total, nseg);
-  nseg = ceil_div(rb_total, rb_per_seg);
-  const int evcap = 64 + 8 * K;
-  const size_t FS = (size_t)maxf * nseg;
-  ix->rp_list.ensure(maxf); ix->rp_count.ensure(1); ix->rp_overflow.ensure(maxf);
+  const int gy = std::min(maxf, 16);   // y extent of the scan grids
+  // level geometry (in 64-row blocks)
+  const int l0 = std::min(rb_total, RP_L0_BLOCKS);
+  const int l1 = std::min(rb_total - l0, RP_L1_BLOCKS);
+  const int l2 = rb_total - l0 - l1;
+  const int segs1 = ceil_div(l1, RP_L1_SEG);
+  const int per2 = std::max(RP_L2_MIN, ceil_div(l2, RP_L2_SEGS));
+  const int segs2 = ceil_div(l2, per2);
+  ix->rp_list.ensure(maxf); ix->rp_count.ensure(1);
   ix->rp_q.ensure((size_t)maxf * ix->d);
   ix->rp_tables.ensure((size_t)maxf * ix->m_pad * 256);
-  ix->rp_segtop.ensure(FS * K); ix->rp_segcnt.ensure(FS);
-  ix->rp_prefix.ensure(FS * K); ix->rp_precnt.ensure(FS);
-  ix->rp_evv.ensure(FS * evcap); ix->rp_evi.ensure(FS * evcap); ix->rp_evcnt.ensure(FS);
+  ix->rp_segtop.ensure((size_t)maxf * std::max(segs1, 1) * K); ix->rp_segi.ensure((size_t)maxf * std::max(segs1, 1) * K);
+  ix->rp_segcnt.ensure((size_t)maxf * std::max(segs1, 1));
+  ix->rp_l0v.ensure((size_t)maxf * K); ix->rp_l0i.ensure((size_t)maxf * K); ix->rp_l0c.ensure(maxf);
+  ix->rp_prefix.ensure((size_t)maxf * K); ix->rp_precnt.ensure(maxf);
+  ix->rp_evv.ensure((size_t)maxf * RP_POOL); ix->rp_evi.ensure((size_t)maxf * RP_POOL); ix->rp_evcnt.ensure(maxf);
   HIP_CHECK(hipMemsetAsync(ix->rp_count.p, 0, sizeof(int), st));
-  HIP_CHECK(hipMemsetAsync(ix->rp_overflow.p, 0, sizeof(int) * maxf, st));
+  HIP_CHECK(hipMemsetAsync(ix->rp_evcnt.p, 0, sizeof(int) * maxf, st));
   hipLaunchKernelGGL(rp_collect, dim3(ceil_div(B, 256)), dim3(256), 0, st, d_of, B, maxf, ix->rp_list.p,
                      ix->rp_count.p);
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)maxf * ix->d, 256)), dim3(256), 0, st, dQ, ix->d,
                      maxf, ix->rp_list.p, ix->rp_count.p, ix->rp_q.p);
   launch_build_tables(1, ix, ix->rp_q.p, maxf, maxf, ix->rp_tables.p, st, ix->rp_count.p);
   const size_t lds = (size_t)ix->m_pad * 256 * sizeof(float);
-#define SEG(V, PH)                                                                                                 \
-  do {                                                                                                             \
-    auto kern = rp_seg_scan<V, PH>;                                                                                \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds));                                                                      \
-    hipLaunchKernelGGL(kern, dim3(nseg, gy), dim3(64), lds, st, ix->codes.p, ix->ng, ix->m_pad,                  \
-                       ix->rp_tables.p, ix->rp_count.p, maxf, from, until, ix->row_base, rb_begin, rb_end, rb_per_seg,   \
-                       nseg, K, ix->rp_segtop.p, ix->rp_segcnt.p, ix->rp_prefix.p, ix->rp_precnt.p, evcap,          \
-                       ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p, ix->rp_overflow.p);                             \
-  } while (0)
-  if (ix->vec == 16) SEG(16, 0); else SEG(4, 0);
-  hipLaunchKernelGGL(rp_prefix, dim3(std::min(maxf, 64)), dim3(64), 0, st, ix->rp_segtop.p, ix->rp_segcnt.p, ix->rp_count.p,
-                     maxf, nseg, K, ix->rp_prefix.p, ix->rp_precnt.p);
-  if (ix->vec == 16) SEG(16, 1); else SEG(4, 1);
-#undef SEG
-  hipLaunchKernelGGL(rp_heap, dim3(std::min(maxf, 64)), dim3(64), 0, st, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p,
-                     ix->rp_overflow.p, ix->rp_list.p, ix->rp_count.p, maxf, nseg, evcap, K, d_oi, d_od, d_oc, d_of);
+  auto scan = [&](int rb_lo, int rb_hi, int per_seg, int nseg, const float *sv, const int *sc, float *ov, int *oi,
+                  int *oc) {
+    if (nseg <= 0) return;
+    auto kern = ix->vec == 16 ? rp_scan<16> : rp_scan<4>;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(nseg, 4), gy), dim3(256), lds, st, ix->codes.p, ix->ng, ix->m_pad,
+                       ix->rp_tables.p, ix->rp_count.p, maxf, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K,
+                       sv, sc, ov, oi, oc, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p);
+    HIP_CHECK(hipGetLastError());
+  };
+  // level 0: cold start over the first rows -> their K smallest distances
+  scan(rb_begin, rb_begin + l0, l0, 1, nullptr, nullptr, ix->rp_l0v.p, ix->rp_l0i.p, ix->rp_l0c.p);
+  const float *cur_v = ix->rp_l0v.p;
+  const int *cur_c = ix->rp_l0c.p;
+  if (segs1 > 0) {
+    scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, cur_v, cur_c, ix->rp_segtop.p, ix->rp_segi.p,
+         ix->rp_segcnt.p);
+    if (segs2 > 0) {
+      hipLaunchKernelGGL(rp_merge, dim3(std::min(maxf, 64)), dim3(64), 0, st, cur_v, cur_c, ix->rp_segtop.p,
+                         ix->rp_segi.p, ix->rp_count.p, maxf, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
+      HIP_CHECK(hipGetLastError());
+      scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr);
+    }
+  }
+  unsigned long long *dbgp = nullptr;
+  if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
+  const size_t heap_lds = (size_t)(2 * RP_POOL + 2 * RP_KEEP) * sizeof(float);
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rp_heap), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)heap_lds));
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(maxf, 64)), dim3(256), heap_lds, st, ix->rp_evv.p, ix->rp_evi.p,
+                     ix->rp_evcnt.p, ix->rp_list.p, ix->rp_count.p, maxf, K, d_oi, d_od, d_oc, d_of, dbgp);
   HIP_CHECK(hipGetLastError());
+  if (dbgp) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long h[6];
+    HIP_CHECK(hipMemcpy(h, dbgp, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[replay] rp_heap phases (us): load %.1f sort %.1f events %.1f heap %.1f; inserting rows %llu\n",
+            (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, h[5]);
+  }
+  if (getenv("GULON_REPLAY_STATS")) {   // debugging aid: synchronous candidate counts
+    HIP_CHECK(hipStreamSynchronize(st));
+    int nf = 0;
+    HIP_CHECK(hipMemcpy(&nf, ix->rp_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    nf = std::min(nf, maxf);
+    std::vector<int> h((size_t)std::max(nf, 1));
+    if (nf) HIP_CHECK(hipMemcpy(h.data(), ix->rp_evcnt.p, sizeof(int) * nf, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[replay] %d flagged queries; levels %d + %d x %d + %d x %d blocks; candidates:", nf, l0, segs1,
+            RP_L1_SEG, segs2, per2);
+    for (int i = 0; i < nf && i < 16; i++) fprintf(stderr, " %d", h[i]);
+    fprintf(stderr, "\n");
+  }
 }
 
 }  // namespace gulon

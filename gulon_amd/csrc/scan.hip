@@ -692,8 +692,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->profile) {
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
+    e0 = ix->take_event();
+    e1 = ix->take_event();
     HIP_CHECK(hipEventRecord(e0, st));
   }
   launch_scan(ix, ntiles, nchunks, rb_begin, rb_total, rb_per_chunk, all, from, until, keff, st);
@@ -841,10 +841,16 @@ GULON_API int32_t gulon_index_profile(gulon_index *idx, int32_t enable) {
   return guarded([&] {
     GULON_REQUIRE(idx != nullptr, "index is null");
     std::lock_guard<std::mutex> lock(idx->mu);
-    for (auto &e : idx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     idx->events.clear();
+    idx->ev_next = 0;
     idx->prof_rows = 0;
     idx->profile = enable != 0;
+    if (idx->profile)
+      while (idx->ev_pool.size() < 512) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreate(&e));
+        idx->ev_pool.push_back(e);
+      }
   });
 }
 

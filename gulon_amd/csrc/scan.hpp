@@ -43,8 +43,8 @@ struct gulon_index {
   DevBuf<float> peel_v, peel_tv, peel_lbv;
   DevBuf<int> peel_i, peel_ti, peel_lbi;
   // exact tie replay (replay.hip)
-  DevBuf<int> rp_list, rp_count, rp_segcnt, rp_evcnt, rp_overflow, rp_evi, rp_precnt;
-  DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv;
+  DevBuf<int> rp_list, rp_count, rp_segcnt, rp_segi, rp_evcnt, rp_evi, rp_precnt, rp_l0i, rp_l0c;
+  DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv, rp_l0v;
   // quantized lower-bound filter (filter.hip)
   DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
   DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;
@@ -52,10 +52,20 @@ struct gulon_index {
   // optional hipEvent bracketing of the dominant scan kernel (bench.py roofline line)
   bool profile = false;
   long long prof_rows = 0;          // rows covered by the bracketed launches
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded pairs (events belong to ev_pool)
+  std::vector<hipEvent_t> ev_pool;  // created once: hipEventCreate inside the timed region is slow
+  size_t ev_next = 0;
   std::mutex mu;
+  hipEvent_t take_event() {
+    if (ev_next == ev_pool.size()) {
+      hipEvent_t e = nullptr;
+      HIP_CHECK(hipEventCreate(&e));
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_next++];
+  }
   ~gulon_index() {
-    for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : ev_pool) (void)hipEventDestroy(e);
   }
 };
 
@@ -81,9 +91,9 @@ struct ScanTuning {
   int filter_period = 128;   // row blocks per sampling period
   int filter_sample = 32768; // sample rows whose exact distances give the initial bounds
   int filter_stage0 = 0;     // blocks per period scanned by an extra first filter stage (0: none)
-  int filter_stage1 = 12;    // blocks per period scanned by the second filter stage
+  int filter_stage1 = 6;     // blocks per period scanned by the second filter stage
   int filter_cap = 32768;    // survivor queue entries per query and stage
-  int filter_nadd = 2;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels)
+  int filter_nadd = 4;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch
   ScanTuning();
   bool set(const char *key, int v);

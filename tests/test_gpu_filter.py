@@ -13,8 +13,8 @@ from test_gpu_query import _check, _make
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_MIN_RB": 8192, "GULON_FILTER_PERIOD": 128,
-            "GULON_FILTER_STAGE0": 2, "GULON_FILTER_STAGE1": 12, "GULON_FILTER_CAP": 32768,
-            "GULON_FILTER_NADD": 2, "GULON_FILTER_SAMPLE": 4096}
+            "GULON_FILTER_STAGE0": 0, "GULON_FILTER_STAGE1": 6, "GULON_FILTER_CAP": 32768,
+            "GULON_FILTER_NADD": 4, "GULON_FILTER_SAMPLE": 32768}
 
 
 @pytest.fixture(scope="module")
