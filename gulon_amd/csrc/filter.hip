@@ -329,21 +329,27 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   }
 }
 
-// ---- exact re-evaluation of the survivors; one wave per query --------------------------------
+// ---- exact re-evaluation of the survivors; one workgroup (4 waves) per query -------------------
+// Wave 0 continues the query's running (K+1)-list; waves 1-3 collect into empty lists but only
+// what beats the running list's last entry; the four lists are merged through LDS at the end.
+constexpr int SV_WAVES = 4;
 template <int VEC>
-__global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict__ codes, int ng, int m_pad,
-                                                       const float *__restrict__ tables, int row_base,
-                                                       int *__restrict__ cnt, const int *__restrict__ queue, int cap,
-                                                       int B, int keff, float *__restrict__ fin_v,
-                                                       int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt) {
+__global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
+    const uint8_t *__restrict__ codes, int ng, int m_pad, const float *__restrict__ tables, int row_base,
+    int *__restrict__ cnt, const int *__restrict__ queue, int cap, int B, int keff, float *__restrict__ fin_v,
+    int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt) {
   using Word = typename CodeWord<VEC>::type;
-  const int q = blockIdx.x, lane = threadIdx.x;
+  __shared__ float mv[(SV_WAVES - 1) * 64];
+  __shared__ int mi[(SV_WAVES - 1) * 64];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // sub-queue fill levels -> exclusive offsets of a flat numbering of this query's survivors
   int mine = lane < NSLOT ? cnt[q * NSLOT + lane] : 0;
-  if (lane < NSLOT) cnt[q * NSLOT + lane] = 0;
+  __syncthreads();                                  // every wave has read the counters
+  if (wave == 0 && lane < NSLOT) cnt[q * NSLOT + lane] = 0;
   if (q >= B) return;
   if (__ballot(mine > cap) != 0ull) {
-    if (lane == 0) fb_tile[q / qt] = 1;   // a sub-queue overflowed: the exact scan redoes this query tile
+    if (tid == 0) fb_tile[q / qt] = 1;   // a sub-queue overflowed: the exact scan redoes this query tile
     mine = min(mine, cap);
   }
   int incl = mine;
@@ -366,25 +372,31 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
     return queue[((size_t)q * NSLOT + sl) * cap + (e - off)];
   };
 
+  // the running list, and its last entry as the admission bound of the helper waves
+  const float fv = lane < keff ? fin_v[(size_t)q * keff + lane] : INFINITY;
+  const int fi = lane < keff ? fin_i[(size_t)q * keff + lane] : INT_MAX;
+  const float bound_v = readlane_f(fv, keff - 1);
+  const int bound_i = readlane_i(fi, keff - 1);
   WaveList wl;
-  wl.v = lane < keff ? fin_v[(size_t)q * keff + lane] : INFINITY;
-  wl.i = lane < keff ? fin_i[(size_t)q * keff + lane] : INT_MAX;
-  wl.tau = readlane_f(wl.v, keff - 1);
-  wl.tau_i = readlane_i(wl.i, keff - 1);
+  wl.init();
+  if (wave == 0) { wl.v = fv; wl.i = fi; wl.tau = bound_v; wl.tau_i = bound_i; }
   // W = 4 interleaved fp32 tables: entry (j, c) of query q at ((q/4 * m_pad + j) * 256 + c) * 4 + q%4
   const float *tq = tables + (size_t)(q >> 2) * m_pad * 1024 + (q & 3);
   const Word *cw = reinterpret_cast<const Word *>(codes);
-  // two-deep software pipeline: row ids two batches ahead, first code word one batch ahead
-  int row_n = lane < n ? entry(lane) : 0;
+  // survivors e = (SV_WAVES * it + wave) * 64 + lane; two-deep software pipeline: row ids two
+  // batches ahead, first code word one batch ahead
+  constexpr int STEP = 64 * SV_WAVES;
+  const int e0 = wave * 64 + lane;
+  int row_n = e0 < n ? entry(e0) : 0;
   Word w_n = cw[((size_t)(row_n >> 6) * ng) * 64 + (row_n & 63)];
-  int row_nn = 64 + lane < n ? entry(64 + lane) : 0;
-  for (int base = 0; base < n; base += 64) {
-    const bool have = base + lane < n;
+  int row_nn = e0 + STEP < n ? entry(e0 + STEP) : 0;
+  for (int e = e0; e - lane < n; e += STEP) {
+    const bool have = e < n;
     const int row = row_n;
     const Word w0 = w_n;
     row_n = row_nn;
     w_n = cw[((size_t)(row_n >> 6) * ng) * 64 + (row_n & 63)];
-    row_nn = base + 128 + lane < n ? entry(base + 128 + lane) : 0;
+    row_nn = e + 2 * STEP < n ? entry(e + 2 * STEP) : 0;
     float d = 0.f;                      // the reference's order: j ascending, unfused fp32
     for (int g = 0; g < ng; g++) {
       const Word w = g == 0 ? w0 : cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
@@ -395,7 +407,8 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
       for (int b = 0; b < VEC; b++) d += t[b];
     }
     const int cr = row + row_base;
-    unsigned long long mk = __ballot(have && wl.accepts(d, cr));
+    const bool in_bound = d < bound_v || (d == bound_v && cr < bound_i);
+    unsigned long long mk = __ballot(have && in_bound && wl.accepts(d, cr));
     while (mk) {
       const int l = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
@@ -404,9 +417,20 @@ __global__ __launch_bounds__(64) void survivors_kernel(const uint8_t *__restrict
       if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
     }
   }
-  if (lane < keff) {
-    fin_v[(size_t)q * keff + lane] = wl.v;
-    fin_i[(size_t)q * keff + lane] = wl.i;
+  if (wave > 0) { mv[(wave - 1) * 64 + lane] = wl.v; mi[(wave - 1) * 64 + lane] = wl.i; }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w2 = 0; w2 < SV_WAVES - 1; w2++)
+      for (int e = 0; e < keff; e++) {
+        const float v = mv[w2 * 64 + e];
+        const int r = mi[w2 * 64 + e];
+        if (r == INT_MAX) break;      // sorted: the rest is padding
+        if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
+      }
+    if (lane < keff) {
+      fin_v[(size_t)q * keff + lane] = wl.v;
+      fin_i[(size_t)q * keff + lane] = wl.i;
+    }
   }
 }
 
@@ -498,7 +522,9 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 
   launch_build_tables(4, ix, dQ, B, Bp, ix->tables.p, st);
   {   // bounds from a strided sample of about filter_sample rows; resets the running lists
-    int sblocks = std::max(NW, std::min(rb_total, ceil_div(t.filter_sample, 64)));
+    // about 1/256 of the rows, at most filter_sample: small shards need (and can afford) less
+    const int srows = std::max(4096, std::min(t.filter_sample, rb_total / 4));
+    int sblocks = std::max(NW, std::min(rb_total, ceil_div(srows, 64)));
     const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
     const int se = rbmap_count(rb_total, smap);
     const size_t lds_bytes = std::max((size_t)ix->m_pad * 256 * 16, (size_t)4 * NW * 64 * 4);
@@ -553,11 +579,11 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       ix->prof_rows += std::min<long long>((long long)en * 64, (long long)until - from);
     }
     if (ix->vec == 16)
-      hipLaunchKernelGGL(survivors_kernel<16>, dim3(Bq), dim3(64), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
+      hipLaunchKernelGGL(survivors_kernel<16>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
                          ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
                          ix->fb_tile.p, QT);
     else
-      hipLaunchKernelGGL(survivors_kernel<4>, dim3(Bq), dim3(64), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
+      hipLaunchKernelGGL(survivors_kernel<4>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
                          ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
                          ix->fb_tile.p, QT);
     HIP_CHECK(hipGetLastError());
