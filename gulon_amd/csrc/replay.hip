@@ -29,15 +29,41 @@ namespace gulon {
 
 constexpr int RP_MAXF = 1024;    // flagged queries replayed per batch (all of a 1024-query batch)
 constexpr int RP_POOL = 8192;    // candidate rows kept per flagged query (more: the flagged result stays)
+constexpr int RP_LDS_POOL = 16384;   // candidates rp_heap can sort in LDS (all shards of a query together)
 constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = 2048, RP_L1_SEG = 64, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
 
-__global__ void rp_collect(const int *__restrict__ flags, int B, int maxf, int *__restrict__ list,
-                           int *__restrict__ count) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < B && (flags[q] & (GULON_FLAG_BOUNDARY_TIE | GULON_FLAG_INTERIOR_TIE))) {
-    int p = atomicAdd(count, 1);
-    if (p < maxf) list[p] = q;
+// Candidate buffer ("pack", int32 words) for F flagged queries with C candidates each:
+//   [0] number of flagged queries (<= F)   [1] F   [2] C   [3] -
+//   [4, 4+F) query ids, ascending          [4+F, 4+2F) candidates written per query
+//   then F*C distances (float bits), then F*C global row ids.
+// One pack per row shard; rp_heap consumes the packs of all shards of a query together.
+struct Pack {
+  int *base; int F, C;
+  __host__ __device__ int *count() const { return base; }
+  __host__ __device__ int *list() const { return base + 4; }
+  __host__ __device__ int *evcnt() const { return base + 4 + F; }
+  __host__ __device__ float *evv() const { return reinterpret_cast<float *>(base + 4 + 2 * F); }
+  __host__ __device__ int *evi() const { return base + 4 + 2 * F + (size_t)F * C; }
+};
+size_t replay_pack_words(int F, int C) { return 4 + 2 * (size_t)F + 2 * (size_t)F * C; }
+
+// flagged queries in ascending order (deterministic: every shard builds the same list); one wave
+__global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, int B, Pack pk) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int q0 = 0; q0 < B; q0 += 64) {
+    const int q = q0 + lane;
+    const bool fl = q < B && (flags[q] & (GULON_FLAG_BOUNDARY_TIE | GULON_FLAG_INTERIOR_TIE));
+    const unsigned long long mk = __ballot(fl);
+    const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+    if (fl && pos < pk.F) pk.list()[pos] = q;
+    base += __popcll(mk);
   }
+  for (int f = lane; f < pk.F; f += 64) {
+    pk.evcnt()[f] = 0;
+    if (f >= base) pk.list()[f] = -1;
+  }
+  if (lane == 0) { pk.count()[0] = min(base, pk.F); pk.count()[1] = pk.F; pk.count()[2] = pk.C; pk.count()[3] = 0; }
 }
 
 __global__ void rp_gather_queries(const float *__restrict__ Q, int d, int maxf, const int *__restrict__ list,
@@ -68,7 +94,7 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
                                                int row_base, int rb_lo, int rb_hi, int rb_per_seg, int nseg, int K,
                                                const float *__restrict__ start_v, const int *__restrict__ start_c,
                                                float *__restrict__ out_v, int *__restrict__ out_i,
-                                               int *__restrict__ out_c, float *__restrict__ evv,
+                                               int *__restrict__ out_c, int pool, float *__restrict__ evv,
                                                int *__restrict__ evi, int *__restrict__ evcnt) {
   using Word = typename RpWord<VEC>::type;
   extern __shared__ float tab[];   // m_pad * 256
@@ -99,9 +125,9 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
       int base = 0;
       if (lane == 0) base = atomicAdd(&evcnt[f], npend);
       base = readlane_i(base, 0);
-      if (lane < npend && base + lane < RP_POOL) {
-        evv[(size_t)f * RP_POOL + base + lane] = pv;
-        evi[(size_t)f * RP_POOL + base + lane] = pi;
+      if (lane < npend && base + lane < pool) {
+        evv[(size_t)f * pool + base + lane] = pv;
+        evi[(size_t)f * pool + base + lane] = pi;
       }
       npend = 0;
     };
@@ -187,30 +213,46 @@ __global__ __launch_bounds__(64) void rp_merge(const float *__restrict__ start_v
 //      insert (distance below the K-th smallest so far) -- the rest would be rejected by the heap;
 //   3. wave 0 pushes those through the heap (kept in registers, lane = slot) and drains it.
 constexpr int RP_KEEP = 2048;
-__global__ __launch_bounds__(256) void rp_heap(const float *__restrict__ evv, const int *__restrict__ evi,
-                                               const int *__restrict__ evcnt, const int *__restrict__ list,
-                                               const int *__restrict__ count, int maxf, int K,
-                                               int *__restrict__ out_idx, float *__restrict__ out_dist,
-                                               int *__restrict__ out_count, int *__restrict__ out_flags,
-                                               unsigned long long *__restrict__ dbg) {
+__global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, int lists, long long stride_words, int F,
+                                               int C, int lds_pool, int K, int *__restrict__ out_idx,
+                                               float *__restrict__ out_dist, int *__restrict__ out_count,
+                                               int *__restrict__ out_flags, unsigned long long *__restrict__ dbg) {
   extern __shared__ float rp_lds[];
-  float *cv = rp_lds;                                         // [RP_POOL] candidate distances
-  int *ci = reinterpret_cast<int *>(rp_lds + RP_POOL);        // [RP_POOL] candidate rows
-  float *sv = rp_lds + 2 * RP_POOL;                           // [RP_KEEP] inserting rows, in row order
-  int *si = reinterpret_cast<int *>(rp_lds + 2 * RP_POOL + RP_KEEP);
+  float *cv = rp_lds;                                          // [lds_pool] candidate distances
+  int *ci = reinterpret_cast<int *>(rp_lds + lds_pool);        // [lds_pool] candidate rows
+  float *sv = rp_lds + 2 * lds_pool;                           // [RP_KEEP] inserting rows, in row order
+  int *si = reinterpret_cast<int *>(rp_lds + 2 * lds_pool + RP_KEEP);
   __shared__ int nkeep;
   const int tid = threadIdx.x;
-  const int nf = min(*count, maxf);
+  const Pack p0{const_cast<int *>(packs), F, C};
+  const int nf = min(p0.count()[0], F);
   for (int f = blockIdx.x; f < nf; f += gridDim.x) {
     __syncthreads();
-    const int total = evcnt[f];
-    if (total > RP_POOL) continue;   // too many candidates: keeps the (distance, row id) result and its tie flags
+    // candidates of query f from every shard (list): concatenate, then sort by row id
+    int total = 0;
+    bool ok = true;
+    for (int l = 0; l < lists; l++) {
+      const Pack pk{const_cast<int *>(packs) + (size_t)l * stride_words, F, C};
+      const int c = pk.evcnt()[f];
+      ok = ok && c <= C;
+      total += min(c, C);
+    }
+    if (!ok || total > lds_pool) continue;   // too many candidates: keeps the (distance, row id) result and its flags
     if (dbg && tid == 0 && f == 0) dbg[0] = wall_clock64();
     int n2 = 64;
     while (n2 < total) n2 <<= 1;
-    for (int e = tid; e < n2; e += 256) {
-      ci[e] = e < total ? evi[(size_t)f * RP_POOL + e] : INT_MAX;
-      cv[e] = e < total ? evv[(size_t)f * RP_POOL + e] : INFINITY;
+    {
+      int off = 0;
+      for (int l = 0; l < lists; l++) {
+        const Pack pk{const_cast<int *>(packs) + (size_t)l * stride_words, F, C};
+        const int c = pk.evcnt()[f];
+        for (int e = tid; e < c; e += 256) {
+          ci[off + e] = pk.evi()[(size_t)f * C + e];
+          cv[off + e] = pk.evv()[(size_t)f * C + e];
+        }
+        off += c;
+      }
+      for (int e = total + tid; e < n2; e += 256) { ci[e] = INT_MAX; cv[e] = INFINITY; }
     }
     __syncthreads();
     if (dbg && tid == 0 && f == 0) dbg[1] = wall_clock64();
@@ -308,7 +350,7 @@ __global__ __launch_bounds__(256) void rp_heap(const float *__restrict__ evv, co
           }
         }
       }
-      const int q = list[f];
+      const int q = p0.list()[f];
       const int live = size;
       for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
         const float tv = readlane_f(hv, 0);
@@ -326,12 +368,15 @@ __global__ __launch_bounds__(256) void rp_heap(const float *__restrict__ evv, co
   }
 }
 
-void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
-                    int *d_oc, int *d_of, hipStream_t st) {
-  if (B <= 0 || K <= 0 || until <= from) return;
+// Candidates of the flagged queries over rows [from, until) of this index (cold start at `from`).
+void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
+                    int C, int *pack, hipStream_t st) {
+  const Pack pk{pack, F, C};
+  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, B, pk);
+  HIP_CHECK(hipGetLastError());
+  if (until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
-  const int maxf = std::min(B, RP_MAXF);
-  const int gy = std::min(maxf, 16);   // y extent of the scan grids
+  const int gy = std::min(F, 16);   // y extent of the scan grids
   // level geometry (in 64-row blocks)
   const int l0 = std::min(rb_total, RP_L0_BLOCKS);
   const int l1 = std::min(rb_total - l0, RP_L1_BLOCKS);
@@ -339,21 +384,15 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
   const int segs1 = ceil_div(l1, RP_L1_SEG);
   const int per2 = std::max(RP_L2_MIN, ceil_div(l2, RP_L2_SEGS));
   const int segs2 = ceil_div(l2, per2);
-  ix->rp_list.ensure(maxf); ix->rp_count.ensure(1);
-  ix->rp_q.ensure((size_t)maxf * ix->d);
-  ix->rp_tables.ensure((size_t)maxf * ix->m_pad * 256);
-  ix->rp_segtop.ensure((size_t)maxf * std::max(segs1, 1) * K); ix->rp_segi.ensure((size_t)maxf * std::max(segs1, 1) * K);
-  ix->rp_segcnt.ensure((size_t)maxf * std::max(segs1, 1));
-  ix->rp_l0v.ensure((size_t)maxf * K); ix->rp_l0i.ensure((size_t)maxf * K); ix->rp_l0c.ensure(maxf);
-  ix->rp_prefix.ensure((size_t)maxf * K); ix->rp_precnt.ensure(maxf);
-  ix->rp_evv.ensure((size_t)maxf * RP_POOL); ix->rp_evi.ensure((size_t)maxf * RP_POOL); ix->rp_evcnt.ensure(maxf);
-  HIP_CHECK(hipMemsetAsync(ix->rp_count.p, 0, sizeof(int), st));
-  HIP_CHECK(hipMemsetAsync(ix->rp_evcnt.p, 0, sizeof(int) * maxf, st));
-  hipLaunchKernelGGL(rp_collect, dim3(ceil_div(B, 256)), dim3(256), 0, st, d_of, B, maxf, ix->rp_list.p,
-                     ix->rp_count.p);
-  hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)maxf * ix->d, 256)), dim3(256), 0, st, dQ, ix->d,
-                     maxf, ix->rp_list.p, ix->rp_count.p, ix->rp_q.p);
-  launch_build_tables(1, ix, ix->rp_q.p, maxf, maxf, ix->rp_tables.p, st, ix->rp_count.p);
+  ix->rp_q.ensure((size_t)F * ix->d);
+  ix->rp_tables.ensure((size_t)F * ix->m_pad * 256);
+  ix->rp_segtop.ensure((size_t)F * std::max(segs1, 1) * K); ix->rp_segi.ensure((size_t)F * std::max(segs1, 1) * K);
+  ix->rp_segcnt.ensure((size_t)F * std::max(segs1, 1));
+  ix->rp_l0v.ensure((size_t)F * K); ix->rp_l0i.ensure((size_t)F * K); ix->rp_l0c.ensure(F);
+  ix->rp_prefix.ensure((size_t)F * K); ix->rp_precnt.ensure(F);
+  hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)F * ix->d, 256)), dim3(256), 0, st, dQ, ix->d, F,
+                     pk.list(), pk.count(), ix->rp_q.p);
+  launch_build_tables(1, ix, ix->rp_q.p, F, F, ix->rp_tables.p, st, pk.count());
   const size_t lds = (size_t)ix->m_pad * 256 * sizeof(float);
   auto scan = [&](int rb_lo, int rb_hi, int per_seg, int nseg, const float *sv, const int *sc, float *ov, int *oi,
                   int *oc) {
@@ -362,31 +401,42 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     hipLaunchKernelGGL(kern, dim3(ceil_div(nseg, 4), gy), dim3(256), lds, st, ix->codes.p, ix->ng, ix->m_pad,
-                       ix->rp_tables.p, ix->rp_count.p, maxf, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K,
-                       sv, sc, ov, oi, oc, ix->rp_evv.p, ix->rp_evi.p, ix->rp_evcnt.p);
+                       ix->rp_tables.p, pk.count(), F, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K, sv, sc,
+                       ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt());
     HIP_CHECK(hipGetLastError());
   };
   // level 0: cold start over the first rows -> their K smallest distances
   scan(rb_begin, rb_begin + l0, l0, 1, nullptr, nullptr, ix->rp_l0v.p, ix->rp_l0i.p, ix->rp_l0c.p);
-  const float *cur_v = ix->rp_l0v.p;
-  const int *cur_c = ix->rp_l0c.p;
   if (segs1 > 0) {
-    scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, cur_v, cur_c, ix->rp_segtop.p, ix->rp_segi.p,
-         ix->rp_segcnt.p);
+    scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
+         ix->rp_segi.p, ix->rp_segcnt.p);
     if (segs2 > 0) {
-      hipLaunchKernelGGL(rp_merge, dim3(std::min(maxf, 64)), dim3(64), 0, st, cur_v, cur_c, ix->rp_segtop.p,
-                         ix->rp_segi.p, ix->rp_count.p, maxf, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
+      hipLaunchKernelGGL(rp_merge, dim3(std::min(F, 64)), dim3(64), 0, st, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
+                         ix->rp_segi.p, pk.count(), F, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
       HIP_CHECK(hipGetLastError());
       scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr);
     }
   }
-  unsigned long long *dbgp = nullptr;
-  if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
-  const size_t heap_lds = (size_t)(2 * RP_POOL + 2 * RP_KEEP) * sizeof(float);
+  if (getenv("GULON_REPLAY_STATS")) {   // debugging aid: synchronous candidate counts
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<int> h(4 + 2 * (size_t)F);
+    HIP_CHECK(hipMemcpy(h.data(), pack, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[replay] %d flagged queries; levels %d + %d x %d + %d x %d blocks; candidates:", h[0], l0, segs1,
+            RP_L1_SEG, segs2, per2);
+    for (int i = 0; i < h[0] && i < 16; i++) fprintf(stderr, " %d", h[4 + F + i]);
+    fprintf(stderr, "\n");
+  }
+}
+
+// Literal heap over the candidates of `lists` packs (one per row shard, same flagged-query list).
+void replay_apply(const int *packs, int lists, long long stride_words, int F, int C, int K, int *d_oi, float *d_od,
+                  int *d_oc, int *d_of, unsigned long long *dbgp, hipStream_t st) {
+  const int lds_pool = (int)std::min<long long>((long long)lists * C, RP_LDS_POOL);
+  const size_t heap_lds = (size_t)(2 * lds_pool + 2 * RP_KEEP) * sizeof(float);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rp_heap), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)heap_lds));
-  hipLaunchKernelGGL(rp_heap, dim3(std::min(maxf, 64)), dim3(256), heap_lds, st, ix->rp_evv.p, ix->rp_evi.p,
-                     ix->rp_evcnt.p, ix->rp_list.p, ix->rp_count.p, maxf, K, d_oi, d_od, d_oc, d_of, dbgp);
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(F, 64)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
+                     K, d_oi, d_od, d_oc, d_of, dbgp);
   HIP_CHECK(hipGetLastError());
   if (dbgp) {
     HIP_CHECK(hipStreamSynchronize(st));
@@ -395,18 +445,51 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
     fprintf(stderr, "[replay] rp_heap phases (us): load %.1f sort %.1f events %.1f heap %.1f; inserting rows %llu\n",
             (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, h[5]);
   }
-  if (getenv("GULON_REPLAY_STATS")) {   // debugging aid: synchronous candidate counts
-    HIP_CHECK(hipStreamSynchronize(st));
-    int nf = 0;
-    HIP_CHECK(hipMemcpy(&nf, ix->rp_count.p, sizeof(int), hipMemcpyDeviceToHost));
-    nf = std::min(nf, maxf);
-    std::vector<int> h((size_t)std::max(nf, 1));
-    if (nf) HIP_CHECK(hipMemcpy(h.data(), ix->rp_evcnt.p, sizeof(int) * nf, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[replay] %d flagged queries; levels %d + %d x %d + %d x %d blocks; candidates:", nf, l0, segs1,
-            RP_L1_SEG, segs2, per2);
-    for (int i = 0; i < nf && i < 16; i++) fprintf(stderr, " %d", h[i]);
-    fprintf(stderr, "\n");
-  }
+}
+
+void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
+                    int *d_oc, int *d_of, hipStream_t st) {
+  if (B <= 0 || K <= 0 || until <= from) return;
+  const int F = std::min(B, RP_MAXF), C = RP_POOL;
+  ix->rp_pack.ensure(replay_pack_words(F, C));
+  unsigned long long *dbgp = nullptr;
+  if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
+  replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st);
+  replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st);
 }
 
 }  // namespace gulon
+
+using namespace gulon;
+
+// ---- row-sharded replay (one pack per shard, exchanged by the caller) ------------------------
+GULON_API int64_t gulon_replay_pack_words(void) {
+  return (int64_t)replay_pack_words(GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL);
+}
+
+GULON_API int32_t gulon_index_replay_collect_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                                 int32_t from, int32_t until, const int32_t *d_flags, int32_t *d_pack,
+                                                 void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr && d_pack != nullptr && d_flags != nullptr, "null argument");
+    GULON_REQUIRE(from <= until && from >= 0 && until <= idx->n, "expected: 0 <= from <= until <= length");
+    GULON_REQUIRE(b >= 0 && k_nn >= 1, "bad shape");
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    replay_collect(idx, d_queries, b, k_nn, from, until, d_flags, GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL, d_pack,
+                   (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t b, int32_t k_nn,
+                                         int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
+                                         int32_t *d_out_flags, void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(d_packs != nullptr && lists >= 1 && b >= 0 && k_nn >= 1, "bad arguments");
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    GULON_REQUIRE(d_out_idx && d_out_dist && d_out_flags, "null output");
+    replay_apply(d_packs, lists, (long long)replay_pack_words(GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL),
+                 GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL, k_nn, d_out_idx, d_out_dist, d_out_count, d_out_flags,
+                 nullptr, (hipStream_t)stream);
+  });
+}

@@ -43,8 +43,8 @@ struct gulon_index {
   DevBuf<float> peel_v, peel_tv, peel_lbv;
   DevBuf<int> peel_i, peel_ti, peel_lbi;
   // exact tie replay (replay.hip)
-  DevBuf<int> rp_list, rp_count, rp_segcnt, rp_segi, rp_evcnt, rp_evi, rp_precnt, rp_l0i, rp_l0c;
-  DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_evv, rp_l0v;
+  DevBuf<int> rp_pack, rp_segcnt, rp_segi, rp_precnt, rp_l0i, rp_l0c;
+  DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_l0v;
   // quantized lower-bound filter (filter.hip)
   DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
   DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;

@@ -9,6 +9,9 @@ TopKHeap.merge semantics (TopKHeap.scala:44-53, used the same way by
 Index.scala:279) under the deterministic (distance, row id) order, so the
 result does not depend on the number of shards.
 
+Queries flagged with an exact distance tie are then replayed with the reference's heap
+semantics from the candidate rows of all shards (a second, fixed-size all-gather).
+
 The compute engine is pluggable only so that the orchestration (bounds, row
 bases, gather layout) can be exercised on CPU with the gloo backend in tests;
 the shipped engine is HipEngine (libgulon_hip.so) and nothing else.
@@ -45,6 +48,8 @@ class HipEngine:
         self.device = device
         self.index = PQIndex(pq, shard, row_base=row_base)
         self.nloc = shard.length
+        # int32 words of one shard's candidate buffer for the exact replay of tie-flagged queries
+        self.replay_words = int(N.lib().gulon_replay_pack_words())
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -75,6 +80,15 @@ class HipEngine:
         """(float32 view of the distance half, int32 row-id half) of a [2*B][K+1] int32 buffer."""
         return pk[:b].view(self.torch.float32), pk[b:]
 
+    def replay_collect(self, q, b, k, of, pack):
+        """This shard's candidate rows for the TopKHeap replay of the flagged queries."""
+        N.check(N.lib().gulon_index_replay_collect_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, of.data_ptr(),
+                                                       pack.data_ptr(), self._stream()))
+
+    def replay_apply(self, packs, lists, b, k, oi, od, oc, of):
+        N.check(N.lib().gulon_replay_apply_dev(packs.data_ptr(), lists, b, k, oi.data_ptr(), od.data_ptr(),
+                                               oc.data_ptr(), of.data_ptr(), self._stream()))
+
 
 class ShardedIndex:
     """One rank's view of the row-sharded flat index."""
@@ -101,7 +115,20 @@ class ShardedIndex:
                 pk=e.alloc((2 * b, k + 1), "i32"),
                 # gathered, rank-major: [world][2][B][K+1]
                 apk=e.alloc((self.world * 2 * b, k + 1), "i32"))
+            words = getattr(e, "replay_words", 0)
+            if words and self.world > 1:
+                self._bufs[key]["rp"] = e.alloc((words,), "i32")
+                self._bufs[key]["arp"] = e.alloc((self.world * words,), "i32")
         return self._bufs[key]
+
+    def _all_gather(self, out, inp):
+        if self.host_staged:
+            # rehearsal path (gloo has no device collectives): same layout, staged through the host
+            hi, ho = inp.cpu(), out.cpu()
+            self.dist.all_gather_into_tensor(ho, hi)
+            out.copy_(ho)
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
 
     def batch_query_dev(self, q, b, k):
         """Enqueue one batch; returns the (device) output tensors idx, dist, count, flags."""
@@ -111,14 +138,14 @@ class ShardedIndex:
         else:
             pv, pi = self.engine.views(u["pk"], b)
             self.engine.scan_partial(q, b, k, pv, pi)
-            if self.host_staged:
-                # rehearsal path (gloo has no device collectives): same layout, staged through the host
-                hp, gp = u["pk"].cpu(), u["apk"].cpu()
-                self.dist.all_gather_into_tensor(gp, hp)
-                u["apk"].copy_(gp)
-            else:
-                self.dist.all_gather_into_tensor(u["apk"], u["pk"])
+            self._all_gather(u["apk"], u["pk"])
             self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
+            if "rp" in u:
+                # queries with exact distance ties: every shard contributes the rows that may insert into
+                # the reference's heap, the union is replayed identically on every rank (TopKHeap.scala:57-79)
+                self.engine.replay_collect(q, b, k, u["of"], u["rp"])
+                self._all_gather(u["arp"], u["rp"])
+                self.engine.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
         return u["oi"], u["od"], u["oc"], u["of"]
 
     def batch_query(self, k, queries):

@@ -183,6 +183,24 @@ int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, in
 int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
                                      int32_t from, int32_t until, float *d_part_dist,
                                      int32_t *d_part_idx, void *stream);
+/* Exact TopKHeap replay of tie-flagged queries across ROW SHARDS (the unsharded
+ * gulon_index_batch_query* does this internally).  After gulon_topk_merge_dev every shard holds
+ * the same flags; each shard then collects, for the first GULON_REPLAY_MAX_FLAGGED flagged
+ * queries, the rows of its range that may insert into the reference's heap (a superset, with
+ * global row ids) into a fixed-size buffer of gulon_replay_pack_words() int32 words; the
+ * buffers of all shards (in row order: shard 0 first), laid out back to back, go to
+ * gulon_replay_apply_dev, which runs the literal TopKHeap (TopKHeap.scala:57-79) over their
+ * union and overwrites idx/dist/count of those queries, setting GULON_FLAG_EXACT_REPLAY.
+ * Further flagged queries, or one with more than GULON_REPLAY_POOL candidates in a shard, keep
+ * the (distance, row id) result and their tie flags. */
+#define GULON_REPLAY_MAX_FLAGGED 16
+#define GULON_REPLAY_POOL 2048
+int64_t gulon_replay_pack_words(void);
+int32_t gulon_index_replay_collect_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                       int32_t from, int32_t until, const int32_t *d_flags, int32_t *d_pack,
+                                       void *stream);
+int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t b, int32_t k_nn, int32_t *d_out_idx,
+                               float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);
 /* Kernel timing for the roofline line of bench.py: when enabled, every scan-kernel
  * launch of this index is bracketed by hipEvents on the launch stream;
  * gulon_index_profile_read synchronises them and returns the summed duration. */

@@ -14,9 +14,16 @@ import torch.multiprocessing as mp
 INT_MAX = 2 ** 31 - 1
 
 
+FLAGGED = 4     # flagged queries the test double replays per batch
+
+
 class OracleEngine:
-    def __init__(self, oracle, idx_local, d, k, cents, row_base):
+    def __init__(self, oracle, idx_local, d, k, cents, row_base, cap=None):
         self.o, self.idx, self.d, self.k, self.cents, self.row_base = oracle, idx_local, d, k, cents, row_base
+        self.nloc = idx_local.shape[1]
+        self.cap = cap or self.nloc          # rows of the largest shard: every rank's buffer has the same size
+        # candidate buffer: [nflag][rows here][FLAGGED qids][FLAGGED x cap distance bits][FLAGGED x cap row ids]
+        self.replay_words = 2 + FLAGGED + 2 * FLAGGED * self.cap
 
     def alloc(self, shape, dtype):
         return torch.empty(shape, dtype={"f32": torch.float32, "i32": torch.int32}[dtype])
@@ -46,13 +53,64 @@ class OracleEngine:
                           if ai[l, r, e] != INT_MAX)
             top = cand[:k]
             oc[r] = len(top)
-            of[r] = 0
+            f = 0
+            if len(cand) > k and cand[k][0] == cand[k - 1][0]:
+                f |= 1                                            # GULON_FLAG_BOUNDARY_TIE
+            if any(top[e][0] == top[e + 1][0] for e in range(len(top) - 1)):
+                f |= 2                                            # GULON_FLAG_INTERIOR_TIE
+            of[r] = f
             for e, (v, i) in enumerate(top):
                 od[r, e] = v
                 oi[r, e] = i
 
+    def replay_collect(self, q, b, k, of, pack):
+        """Every local row is a candidate (a superset of the inserting rows), with its exact distance."""
+        flagged = [r for r in range(b) if int(of[r]) & 3][:FLAGGED]
+        w = np.zeros(self.replay_words, np.int32)
+        w[0], w[1] = len(flagged), self.nloc
+        w[2:2 + FLAGGED] = -1
+        T = self.o.prepare_query(self.cents, self.d, self.idx.shape[0], self.k, q.numpy())
+        m, n = self.idx.shape
+        for f, r in enumerate(flagged):
+            w[2 + f] = r
+            acc = np.zeros(n, np.float32)
+            for j in range(m):                                    # the reference's order: j ascending, fp32
+                acc = (acc + T[r, j, self.idx[j]]).astype(np.float32)
+            o = 2 + FLAGGED + f * self.cap
+            w[o:o + n] = acc.view(np.int32)
+            o2 = 2 + FLAGGED + FLAGGED * self.cap + f * self.cap
+            w[o2:o2 + n] = np.arange(n, dtype=np.int32) + self.row_base
+        pack.copy_(torch.from_numpy(w))
 
-def _worker(rank, world, port, n, d, m, k, B, K, out):
+    def replay_apply(self, packs, lists, b, k, oi, od, oc, of):
+        """Literal TopKHeap over the union of the shards' candidates, in row order."""
+        w = packs.numpy()
+        per = len(w) // lists
+        nflag = int(w[0])
+        for f in range(nflag):
+            r = int(w[2 + f])
+            rows, dists = [], []
+            for l in range(lists):
+                wl = w[l * per:(l + 1) * per]
+                n = int(wl[1])
+                o = 2 + FLAGGED + f * self.cap
+                o2 = 2 + FLAGGED + FLAGGED * self.cap + f * self.cap
+                rows.append(wl[o2:o2 + n])
+                dists.append(wl[o:o + n].view(np.float32))
+            rows, dists = np.concatenate(rows), np.concatenate(dists)
+            order = np.argsort(rows, kind="stable")
+            h = self.o.TopKHeap(k)
+            for e in order:
+                h.update(int(rows[e]), dists[e])
+            ks, vs = h.drain()
+            oc[r] = len(ks)
+            for e in range(len(ks)):
+                oi[r, e] = int(ks[e])
+                od[r, e] = float(vs[e])
+            of[r] = int(of[r]) | 4                                # GULON_FLAG_EXACT_REPLAY
+
+
+def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,14 +121,20 @@ def _worker(rank, world, port, n, d, m, k, B, K, out):
     rng = np.random.default_rng(0)
     cents = rng.standard_normal(k * d).astype(np.float32)
     idx = rng.integers(0, k, (m, n)).astype(np.int32)
+    if dup:
+        idx[:, -dup:] = idx[:, :dup]          # identical codes in the first and the last shard: distance ties
     Q = rng.standard_normal((B, d)).astype(np.float32)
     lo, hi = shard_bounds(n, world, rank)
-    eng = OracleEngine(oracle, np.ascontiguousarray(idx[:, lo:hi]), d, k, cents, lo)
+    eng = OracleEngine(oracle, np.ascontiguousarray(idx[:, lo:hi]), d, k, cents, lo, cap=-(-n // world))
     sh = ShardedIndex(eng, n, rank, world, dist)
     oi, od, oc, of = sh.batch_query(K, Q)
     ei, ed, ec = oracle.pq_batch_query(idx, d, k, cents, Q, K)
-    ok = bool(np.array_equal(oi, ei) and np.array_equal(od.view(np.uint32), ed.view(np.uint32)) and
-              np.array_equal(oc, ec))
+    ok = bool(np.array_equal(od.view(np.uint32), ed.view(np.uint32)) and np.array_equal(oc, ec))
+    for r in range(B):      # ids: the reference's wherever there is no tie or the tie was replayed
+        if of[r] == 0 or (of[r] & 4):
+            ok = ok and bool(np.array_equal(oi[r], ei[r]))
+    if dup:
+        ok = ok and bool(((of & 3) != 0).any()) and bool(((of & 4) != 0).any())
     t = torch.tensor([1 if ok else 0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -92,6 +156,22 @@ def test_sharded_query_equals_unsharded(world, n):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, 12, 4, 16, 5, 7, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1
+
+
+def test_sharded_tie_replay_equals_reference_heap():
+    """Duplicate rows across shards => tie flags => candidates of all shards gathered and replayed
+    through the literal TopKHeap: ids and order equal the unsharded reference semantics."""
+    world, n = 2, 600
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 8, 2, 4, 3, 5, out, 250)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
