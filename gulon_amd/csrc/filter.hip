@@ -492,12 +492,14 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   const RbMap stages[3] = {{P, 0, s0}, {P, s0, s1}, {P, s0 + s1, P - s0 - s1}};
   const int NW = t.threads / 64;
 
+  // chunks per query tile: enough workgroups to fill the chip, but every workgroup stages its
+  // 128 KiB of tables once, so it should get >= 256 row blocks (16 per wave) where the range allows
   auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
-    int want = ceil_div(target, tiles);
-    int maxc = e_count / (2 * NW);
-    if (maxc < 1) maxc = 1;
-    nchunks = want < maxc ? want : maxc;
-    per = ceil_div(e_count, nchunks);
+    const int most = std::max(1, ceil_div(target, tiles));        // launch-size cap
+    const int fill = std::max(1, ceil_div(256, tiles));           // one workgroup per CU
+    int nc = std::max(fill, std::min(most, e_count / 256));
+    nc = std::min(nc, std::max(1, e_count / NW));                 // at least one block per wave
+    per = ceil_div(e_count, nc);
     nchunks = ceil_div(e_count, per);
   };
 
@@ -522,8 +524,9 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 
   launch_build_tables(4, ix, dQ, B, Bp, ix->tables.p, st);
   {   // bounds from a strided sample of about filter_sample rows; resets the running lists
-    // about 1/256 of the rows, at most filter_sample: small shards need (and can afford) less
-    const int srows = std::max(4096, std::min(t.filter_sample, rb_total / 4));
+    // sample size ~ sqrt(rows): the sample scan costs ~1.4 us per 1000 rows, the first filter
+    // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
+    const int srows = std::max(4096, std::min(t.filter_sample, (int)(17.0 * std::sqrt((double)rb_total * 64.0))));
     int sblocks = std::max(NW, std::min(rb_total, ceil_div(srows, 64)));
     const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
     const int se = rbmap_count(rb_total, smap);

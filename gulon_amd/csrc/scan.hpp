@@ -87,9 +87,9 @@ struct ScanTuning {
   int prune = 1;             // exact early termination on/off
   int prune_from = -1;       // first quantizer index with a pruning checkpoint (-1: m_pad/2)
   int filter = 1;            // quantized lower-bound filter on/off
-  int filter_min_rb = 8192;  // smallest range (in 64-row blocks) the filter is used for
+  int filter_min_rb = 512;   // smallest range (in 64-row blocks) the filter is used for
   int filter_period = 128;   // row blocks per sampling period
-  int filter_sample = 32768; // sample rows whose exact distances give the initial bounds
+  int filter_sample = 65536; // most sample rows whose exact distances give the initial bounds
   int filter_stage0 = 0;     // blocks per period scanned by an extra first filter stage (0: none)
   int filter_stage1 = 6;     // blocks per period scanned by the second filter stage
   int filter_cap = 32768;    // survivor queue entries per query and stage
