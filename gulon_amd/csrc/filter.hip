@@ -20,6 +20,8 @@
 // The rows go through three filter stages over disjoint, strided sets of row blocks (two short
 // ones that tighten tau, then the rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
 // by the exact scan (per query tile, decided on the device), so the filter never changes a result.
+#include <map>
+
 #include "scan.hpp"
 
 namespace gulon {
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
 }
 
 // ---- the filter: lane = row, 16*NQG queries per workgroup, NADD entries summed per byte -------
-template <int NQG, int VEC, int NADD>
+// MAIN only tags the instantiation used for the last (large) stage, so that profilers list it apart
+// from the short first stage.
+template <int NQG, int VEC, int NADD, int MAIN>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const uint4 *__restrict__ qtab, int row_from, int row_until,
     int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue,
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
 
 template <int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
-                     int from, int until, int cap, hipStream_t st) {
+                     int from, int until, int cap, bool main_stage, hipStream_t st) {
   const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * 16;
-  auto kern = filter_kernel<NQG, VEC, NADD>;
+  auto kern = main_stage ? filter_kernel<NQG, VEC, NADD, 1> : filter_kernel<NQG, VEC, NADD, 0>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
@@ -447,11 +451,22 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
   HIP_CHECK(hipGetLastError());
 }
 
+// The filter kernel owns the LDS of every CU, so two of them (query batches in flight on
+// different streams) cannot usefully overlap -- they would only time-slice and blur each other's
+// duration.  Launches are therefore chained through one event per device: a batch's small,
+// latency-bound kernels overlap with another batch's filter, the filters themselves run in turn.
+struct FilterLane {
+  std::mutex mu;
+  std::map<int, hipEvent_t> ev;   // device -> completion of the most recent filter launch
+};
+FilterLane &filter_lane() { static FilterLane l; return l; }
+
 int filter_nqg(const gulon_index *ix) { return (size_t)ix->m_pad * 4096 * 2 <= FILTER_LDS_BUDGET ? 2 : 1; }
 
 void launch_filter(gulon_index *ix, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
-                   int e_per_chunk, RbMap mp, int from, int until, int cap, hipStream_t st) {
-#define GO(Q, V, A) launch_filter_t<Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, st)
+                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, hipStream_t st) {
+#define GO(Q, V, A) \
+  launch_filter_t<Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, st)
   if (ix->vec == 16) {
     if (nqg == 2) { if (nadd == 4) GO(2, 16, 4); else GO(2, 16, 2); }
     else          { if (nadd == 4) GO(1, 16, 4); else GO(1, 16, 2); }
@@ -561,12 +576,29 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
                        ix->fb_tile.p, QT);
     HIP_CHECK(hipGetLastError());
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ix->profile) {
+    const bool main_stage = sidx == 2;
+    const bool timed = ix->profile && main_stage;   // the roofline line is about the main-stage kernel
+    if (timed) {
       ev0 = ix->take_event();
       ev1 = ix->take_event();
-      HIP_CHECK(hipEventRecord(ev0, st));
     }
-    launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, st);
+    {
+      FilterLane &ln = filter_lane();
+      std::lock_guard<std::mutex> lock(ln.mu);
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      auto it = ln.ev.find(dev);
+      if (it == ln.ev.end()) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        it = ln.ev.emplace(dev, e).first;
+      } else if (main_stage) {
+        HIP_CHECK(hipStreamWaitEvent(st, it->second, 0));   // only the main stage takes turns
+      }
+      if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
+      launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage, st);
+      if (main_stage) HIP_CHECK(hipEventRecord(it->second, st));
+    }
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
       HIP_CHECK(hipStreamSynchronize(st));
       std::vector<int> h((size_t)Bq * NSLOT);
@@ -576,7 +608,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       fprintf(stderr, "[filter] stage %d: %d row blocks, %d x %d workgroups, survivors total %lld (%.3g of pairs), "
               "max per sub-queue %d (cap %d)\n", sidx + 1, en, ftiles, nc, tot, (double)tot / ((double)en * 64 * B), mx, cap);
     }
-    if (ix->profile) {
+    if (timed) {
       HIP_CHECK(hipEventRecord(ev1, st));
       ix->events.emplace_back(ev0, ev1);
       ix->prof_rows += std::min<long long>((long long)en * 64, (long long)until - from);
