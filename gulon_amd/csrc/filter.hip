@@ -38,36 +38,38 @@ __device__ inline uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {   // per 16-
   return d;
 }
 
+// fp32 table entry (j, c) of query q; W queries are interleaved per entry (scan.hip build_tables)
+__device__ inline float table_at(const float *__restrict__ tables, int W, int m_pad, int q, int j, int c) {
+  return tables[(((size_t)(q / W) * m_pad + j) * 256 + c) * W + q % W];
+}
+
 // ---- per (query, quantizer) minimum of the fp32 table (NaN entries ignored) ----------------
-__global__ __launch_bounds__(256) void qt_mins(const float4 *__restrict__ tables, int Bp, int m_pad, int k,
+__global__ __launch_bounds__(256) void qt_mins(const float *__restrict__ tables, int W, int Bp, int m_pad, int k,
                                                float *__restrict__ mins) {
   __shared__ unsigned smin[16];
   const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
   if (c < 16) smin[c] = 0x7F800000u;
   __syncthreads();
+#pragma unroll 4
+  for (int u = 0; u < 16; u++) {
+    const int q = g16 * 16 + u;
+    float x = INFINITY;
+    if (q < Bp && c < k) x = table_at(tables, W, m_pad, q, j, c);
+    x = x != x ? INFINITY : x;
 #pragma unroll
-  for (int u4 = 0; u4 < 4; u4++) {
-    const int qg4 = g16 * 4 + u4;
-    float4 t = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    if (qg4 * 4 < Bp && c < k) t = tables[((size_t)qg4 * m_pad + j) * 256 + c];
-    float v[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      float x = v[u] != v[u] ? INFINITY : v[u];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
-      if ((c & 63) == 0) atomicMin(&smin[u4 * 4 + u], __float_as_uint(x));   // entries are >= +0: uint order
-    }
+    for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+    if ((c & 63) == 0) atomicMin(&smin[u], __float_as_uint(x));   // entries are >= +0: uint order
   }
   __syncthreads();
   if (c < 16) mins[(size_t)(g16 * 16 + c) * m_pad + j] = __uint_as_float(smin[c]);
 }
 
 // ---- quantize the tables of one 16-query group against the current bounds --------------------
-__global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ tables, int Bp, int m_pad, int k, int B,
-                                                   const float *__restrict__ mins, const float *__restrict__ fin_v,
-                                                   const int *__restrict__ fin_i, const float *__restrict__ tau0,
-                                                   int keff, int qmax, uint4 *__restrict__ qtab,
+__global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tables, int W, int Bp, int m_pad, int k,
+                                                   int B, const float *__restrict__ mins,
+                                                   const float *__restrict__ fin_v, const int *__restrict__ fin_i,
+                                                   const float *__restrict__ tau0, int keff, int qmax, int QW,
+                                                   uint8_t *__restrict__ qtab /*[Bq/QW][m_pad][256][QW]*/,
                                                    int *__restrict__ fb_tile, int qt) {
   __shared__ double s_delta[16];
   __shared__ float s_min[16];
@@ -81,7 +83,10 @@ __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ ta
       // bound = the sample's, tightened by the running list once that is full
       float tau = tau0[q];
       if (fin_i[(size_t)q * keff + keff - 1] != INT_MAX) tau = fminf(tau, fin_v[(size_t)q * keff + keff - 1]);
-      if (!(tau < INFINITY)) {
+      if (fb_tile[q / qt] != 0) {
+        // this query tile already goes to the exact scan (unusable bound, queue overflow, or a
+        // first stage that let too many rows through): nothing of it is filtered any more
+      } else if (!(tau < INFINITY)) {
         if (j == 0) fb_tile[q / qt] = 1;          // no usable bound: this query is redone exactly
       } else {
         double sum_min = 0.0;
@@ -102,18 +107,16 @@ __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ ta
   uint32_t out[4];
 #pragma unroll
   for (int u4 = 0; u4 < 4; u4++) {
-    const int qg4 = g16 * 4 + u4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool have = qg4 * 4 < Bp && c < k;
-    if (have) t = tables[((size_t)qg4 * m_pad + j) * 256 + c];
-    float v[4] = {t.x, t.y, t.z, t.w};
     uint32_t word = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int s = u4 * 4 + u;
+      const int q = g16 * 16 + s;
+      const bool have = q < Bp && c < k;
+      const float v = have ? table_at(tables, W, m_pad, q, j, c) : 0.f;
       int qv = qmax;
-      if (have && !s_dead[s] && v[u] == v[u]) {
-        double x = ((double)v[u] - (double)s_min[s]) * (1.0 - 8.9e-16);
+      if (have && !s_dead[s] && v == v) {
+        double x = ((double)v - (double)s_min[s]) * (1.0 - 8.9e-16);
         if (x < 0.0) x = 0.0;
         const double r = x / s_delta[s];
         if (r < (double)qmax) {
@@ -125,11 +128,22 @@ __global__ __launch_bounds__(256) void qt_quantize(const float4 *__restrict__ ta
     }
     out[u4] = word;
   }
-  qtab[((size_t)g16 * m_pad + j) * 256 + c] = make_uint4(out[0], out[1], out[2], out[3]);
+  // queries g16*16 .. +15 -> entries of QW bytes: [q / QW][j][c][q % QW]
+  if (QW == 16) {
+    reinterpret_cast<uint4 *>(qtab)[((size_t)g16 * m_pad + j) * 256 + c] = make_uint4(out[0], out[1], out[2], out[3]);
+  } else if (QW == 8) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      reinterpret_cast<uint2 *>(qtab)[((size_t)(g16 * 2 + h) * m_pad + j) * 256 + c] = make_uint2(out[2 * h], out[2 * h + 1]);
+  } else {
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+      reinterpret_cast<uint32_t *>(qtab)[((size_t)(g16 * 4 + h) * m_pad + j) * 256 + c] = out[h];
+  }
 }
 
 // ---- initial bounds from a strided sample of row blocks ---------------------------------------
-// One workgroup per 4 queries, their float4-interleaved fp32 table in LDS, lane = row as in the
+// One workgroup per W queries, their W-interleaved fp32 table in LDS, lane = row as in the
 // exact scan -- but no top-k lists in the loop: every lane only keeps the minimum exact distance
 // of the rows it saw (1024 disjoint groups of rows per workgroup).  Any K+1 group minima belong
 // to K+1 distinct rows, so the (K+1)-th smallest group minimum bounds the final (K+1)-th
@@ -157,30 +171,38 @@ __device__ inline float merge64_asc(float a, float b, int lane) {
   return x;
 }
 
-template <int VEC>
+template <int W> struct FTab;
+template <> struct FTab<4> { using type = float4; };
+template <> struct FTab<2> { using type = float2; };
+template <> struct FTab<1> { using type = float; };
+
+template <int VEC, int W>
 __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__restrict__ codes, int ng, int m_pad,
-                                                             const float4 *__restrict__ tables, int row_from,
+                                                             const float *__restrict__ tables, int row_from,
                                                              int row_until, int rb_begin, int e_count, RbMap mp, int B,
                                                              int keff, float *__restrict__ tau0,
                                                              float *__restrict__ fin_v, int *__restrict__ fin_i) {
   constexpr int NW = FILTER_THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
+  using TV = typename FTab<W>::type;
   extern __shared__ uint4 qlds[];
-  float4 *lds = reinterpret_cast<float4 *>(qlds);
+  TV *lds = reinterpret_cast<TV *>(qlds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qg4 = blockIdx.x;
+  const int qg = blockIdx.x;
   {
-    const int n16 = m_pad * 256;
-    const float4 *src = tables + (size_t)qg4 * n16;
-    for (int e = tid; e < n16; e += FILTER_THREADS) lds[e] = src[e];
+    const int nent = m_pad * 256;
+    const TV *src = reinterpret_cast<const TV *>(tables) + (size_t)qg * nent;
+    for (int e = tid; e < nent; e += FILTER_THREADS) lds[e] = src[e];
   }
   __syncthreads();
   const Word *cw = reinterpret_cast<const Word *>(codes);
   int mp_p = wave / mp.width, mp_r = wave - mp_p * mp.width;
   auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
   auto advance = [&](int &p, int &r) { r += NW; while (r >= mp.width) { r -= mp.width; p++; } };
-  float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  float mn[W];
+#pragma unroll
+  for (int u = 0; u < W; u++) mn[u] = INFINITY;
   Word w_first{};
   if (wave < e_count) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
   for (int e = wave; e < e_count; e += NW) {
@@ -189,31 +211,35 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
     const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
     Word w = w_first;
     if (e + NW < e_count) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};     // the reference's order: j ascending, unfused fp32
+    float acc[W];                            // the reference's order: j ascending, unfused fp32
+#pragma unroll
+    for (int u = 0; u < W; u++) acc[u] = 0.f;
     for (int g = 0; g < ng; g++) {
       Word wn = w;
       if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
-      const float4 *tj = lds + g * VEC * 256;
+      const TV *tj = lds + g * VEC * 256;
 #pragma unroll
       for (int b = 0; b < VEC; b++) {
-        const float4 t = tj[b * 256 + code_byte<VEC>(w, b)];
-        acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+        const TV t = tj[b * 256 + code_byte<VEC>(w, b)];
+        const float *tf = reinterpret_cast<const float *>(&t);
+#pragma unroll
+        for (int u = 0; u < W; u++) acc[u] += tf[u];
       }
       w = wn;
     }
     const int row = rb * 64 + lane;
     if (row >= row_from && row < row_until) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) mn[u] = fminf(mn[u], acc[u]);   // NaN distances are ignored
+      for (int u = 0; u < W; u++) mn[u] = fminf(mn[u], acc[u]);   // NaN distances are ignored
     }
   }
   __syncthreads();                     // the table is dead: reuse LDS for the per-wave sorted minima
   float *sv = reinterpret_cast<float *>(qlds);
 #pragma unroll
-  for (int u = 0; u < 4; u++) sv[(u * NW + wave) * 64 + lane] = sort64_asc(mn[u], lane);
+  for (int u = 0; u < W; u++) sv[(u * NW + wave) * 64 + lane] = sort64_asc(mn[u], lane);
   __syncthreads();
-  if (wave < 4) {
-    const int u = wave, q = qg4 * 4 + u;
+  if (wave < W) {
+    const int u = wave, q = qg * W + u;
     float best = sv[(u * NW) * 64 + lane];
     for (int w2 = 1; w2 < NW; w2++) best = merge64_asc(best, sv[(u * NW + w2) * 64 + lane], lane);
     if (q < B) {
@@ -226,24 +252,39 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
 // ---- the filter: lane = row, 16*NQG queries per workgroup, NADD entries summed per byte -------
 // MAIN only tags the instantiation used for the last (large) stage, so that profilers list it apart
 // from the short first stage.
-template <int NQG, int VEC, int NADD, int MAIN>
+template <int QW> struct QEntry;                     // QW queries (one byte each) per table entry
+template <> struct QEntry<16> { using type = uint4; };
+template <> struct QEntry<8> { using type = uint2; };
+template <> struct QEntry<4> { using type = uint32_t; };
+
+template <int QW, int NQG, int VEC, int NADD, int MAIN>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
-    const uint8_t *__restrict__ codes, int ng, int m_pad, const uint4 *__restrict__ qtab, int row_from, int row_until,
+    const uint8_t *__restrict__ codes, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
     int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue,
-    int cap /* entries per sub-queue */) {
+    int cap /* entries per sub-queue */, const int *__restrict__ fb_tile, int qt, int B) {
   constexpr int NW = FILTER_THREADS / 64;
   constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
+  constexpr int DW = QW / 4;     // dwords per entry
   using Word = typename CodeWord<VEC>::type;
-  extern __shared__ uint4 qlds[];
+  using QE = typename QEntry<QW>::type;
+  extern __shared__ uint4 qlds_raw[];
+  QE *qlds = reinterpret_cast<QE *>(qlds_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, chunk = blockIdx.y;
-  const int tab = m_pad * 256;   // uint4 entries per 16-query group
+  const int tab = m_pad * 256;   // entries per QW-query group
+  {   // every query of this tile already goes to the exact scan: nothing to do here
+    const int q_lo = tile * NQG * QW, q_hi = min(B, q_lo + NQG * QW);
+    bool any_live = false;
+    if (q_hi > q_lo)
+      for (int t = q_lo / qt; t <= (q_hi - 1) / qt; t++) any_live = any_live || fb_tile[t] == 0;
+    if (!any_live) return;
+  }
   const int slot = chunk & (NSLOT - 1);   // spreads the queue-tail atomics of one query over NSLOT counters
   {
-    const int n16 = NQG * tab;
-    const uint4 *src = qtab + (size_t)tile * n16;
-    for (int e = tid; e < n16; e += FILTER_THREADS) qlds[e] = src[e];
+    const int n16 = NQG * tab * QW / 16;   // 16-byte units (tab * QW is a multiple of 16)
+    const uint4 *src = reinterpret_cast<const uint4 *>(qtab) + (size_t)tile * n16;
+    for (int e = tid; e < n16; e += FILTER_THREADS) qlds_raw[e] = src[e];
   }
   __syncthreads();
 
@@ -265,16 +306,16 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
 
     // acc[s][2*dd]   : 16-bit sums of queries 4dd (low half) and 4dd+2 (high half) of group s
     // acc[s][2*dd+1] : queries 4dd+1 and 4dd+3
-    uint32_t acc[NQG][8];
+    uint32_t acc[NQG][2 * DW];
 #pragma unroll
     for (int s = 0; s < NQG; s++)
 #pragma unroll
-      for (int x = 0; x < 8; x++) acc[s][x] = 0;
+      for (int x = 0; x < 2 * DW; x++) acc[s][x] = 0;
 
     for (int g = 0; g < ng; g++) {
       Word wn = w;
       if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
-      const uint4 *tj = qlds + g * VEC * 256;
+      const QE *tj = qlds + g * VEC * 256;
 #pragma unroll
       for (int b = 0; b < VEC; b += NADD) {
         uint32_t c[NADD];
@@ -282,15 +323,18 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
         for (int a = 0; a < NADD; a++) c[a] = code_byte<VEC>(w, b + a);
 #pragma unroll
         for (int s = 0; s < NQG; s++) {
-          uint4 x = tj[b * 256 + c[0] + s * tab];
+          QE x = tj[b * 256 + c[0] + s * tab];
+          uint32_t xs[DW];
+#pragma unroll
+          for (int dd = 0; dd < DW; dd++) xs[dd] = reinterpret_cast<const uint32_t *>(&x)[dd];
 #pragma unroll
           for (int a = 1; a < NADD; a++) {   // bytes cannot carry: NADD * QMAX <= 255
-            const uint4 y = tj[(b + a) * 256 + c[a] + s * tab];
-            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-          }
-          const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+            const QE y = tj[(b + a) * 256 + c[a] + s * tab];
 #pragma unroll
-          for (int dd = 0; dd < 4; dd++) {
+            for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&y)[dd];
+          }
+#pragma unroll
+          for (int dd = 0; dd < DW; dd++) {
             acc[s][2 * dd] += xs[dd] & 0x00FF00FFu;
             acc[s][2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
           }
@@ -302,11 +346,11 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
     uint32_t any = 0;
-    uint32_t left[NQG][8];
+    uint32_t left[NQG][2 * DW];
 #pragma unroll
     for (int s = 0; s < NQG; s++)
 #pragma unroll
-      for (int x = 0; x < 8; x++) {
+      for (int x = 0; x < 2 * DW; x++) {
         left[s][x] = pk_sub_sat_u16(QMAXP, acc[s][x]);   // non-zero half <=> that query keeps this row
         any |= left[s][x];
       }
@@ -314,10 +358,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
 #pragma unroll
       for (int s = 0; s < NQG; s++)
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
+        for (int x = 0; x < 2 * DW; x++) {
           const uint32_t l = valid ? left[s][x] : 0u;
           if (__ballot(l != 0) == 0ull) continue;
-          const int q0 = (tile * NQG + s) * 16 + 4 * (x >> 1) + (x & 1);
+          const int q0 = (tile * NQG + s) * QW + 4 * (x >> 1) + (x & 1);
           if (l & 0xFFFFu) {
             const int sq = q0 * NSLOT + slot;
             const int pos = atomicAdd(&cnt[sq], 1);
@@ -339,9 +383,9 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
 constexpr int SV_WAVES = 4;
 template <int VEC>
 __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
-    const uint8_t *__restrict__ codes, int ng, int m_pad, const float *__restrict__ tables, int row_base,
+    const uint8_t *__restrict__ codes, int ng, int m_pad, const float *__restrict__ tables, int W, int row_base,
     int *__restrict__ cnt, const int *__restrict__ queue, int cap, int B, int keff, float *__restrict__ fin_v,
-    int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt) {
+    int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt, int give_up /* survivors beyond which the filter is abandoned; 0: never */) {
   using Word = typename CodeWord<VEC>::type;
   __shared__ float mv[(SV_WAVES - 1) * 64];
   __shared__ int mi[(SV_WAVES - 1) * 64];
@@ -363,6 +407,12 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
     if (lane >= o) incl += up;
   }
   const int n = readlane_i(incl, NSLOT - 1);
+  if (give_up > 0 && n > give_up) {
+    // the bound lets too many rows through for this query (data without a tail of near rows):
+    // filtering the rest would cost more than it saves -- its tile goes to the exact scan
+    if (tid == 0) fb_tile[q / qt] = 1;
+    return;
+  }
   int start[NSLOT];
 #pragma unroll
   for (int sl = 0; sl < NSLOT; sl++) start[sl] = readlane_i(incl - mine, sl);
@@ -384,8 +434,8 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
   WaveList wl;
   wl.init();
   if (wave == 0) { wl.v = fv; wl.i = fi; wl.tau = bound_v; wl.tau_i = bound_i; }
-  // W = 4 interleaved fp32 tables: entry (j, c) of query q at ((q/4 * m_pad + j) * 256 + c) * 4 + q%4
-  const float *tq = tables + (size_t)(q >> 2) * m_pad * 1024 + (q & 3);
+  // W-interleaved fp32 tables: entry (j, c) of query q at ((q/W * m_pad + j) * 256 + c) * W + q%W
+  const float *tq = tables + (size_t)(q / W) * m_pad * 256 * W + q % W;
   const Word *cw = reinterpret_cast<const Word *>(codes);
   // survivors e = (SV_WAVES * it + wave) * 64 + lane; two-deep software pipeline: row ids two
   // batches ahead, first code word one batch ahead
@@ -406,7 +456,7 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
       const Word w = g == 0 ? w0 : cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
       float t[VEC];
 #pragma unroll
-      for (int b = 0; b < VEC; b++) t[b] = tq[((size_t)(g * VEC + b) * 256 + code_byte<VEC>(w, b)) * 4];
+      for (int b = 0; b < VEC; b++) t[b] = tq[((size_t)(g * VEC + b) * 256 + code_byte<VEC>(w, b)) * W];
 #pragma unroll
       for (int b = 0; b < VEC; b++) d += t[b];
     }
@@ -438,16 +488,17 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
   }
 }
 
-template <int NQG, int VEC, int NADD>
+template <int QW, int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
-                     int from, int until, int cap, bool main_stage, hipStream_t st) {
-  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * 16;
-  auto kern = main_stage ? filter_kernel<NQG, VEC, NADD, 1> : filter_kernel<NQG, VEC, NADD, 0>;
+                     int from, int until, int cap, bool main_stage, int B, hipStream_t st) {
+  const int W_fp32 = ix->w;
+  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW;
+  auto kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1> : filter_kernel<QW, NQG, VEC, NADD, 0>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
-                     reinterpret_cast<const uint4 *>(ix->qtab.p), from, until, rb_begin, e_count, e_per_chunk, mp,
-                     ix->sv_cnt.p, ix->sv_queue.p, cap);
+                     ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
+                     ix->fb_tile.p, W_fp32 * ix->nsub, B);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -461,19 +512,29 @@ struct FilterLane {
 };
 FilterLane &filter_lane() { static FilterLane l; return l; }
 
-int filter_nqg(const gulon_index *ix) { return (size_t)ix->m_pad * 4096 * 2 <= FILTER_LDS_BUDGET ? 2 : 1; }
+// queries per quantized table entry: as many as LDS holds for one group (16 up to m_pad = 36,
+// 8 up to 72, 4 up to 144), and how many such groups a workgroup takes (2 if they fit)
+int filter_qw(const gulon_index *ix) {
+  int qw = 16;
+  while (qw > 4 && (size_t)ix->m_pad * 256 * qw > FILTER_LDS_BUDGET) qw /= 2;
+  return qw;
+}
+int filter_nqg(const gulon_index *ix) {
+  return (size_t)ix->m_pad * 256 * filter_qw(ix) * 2 <= FILTER_LDS_BUDGET ? 2 : 1;
+}
 
-void launch_filter(gulon_index *ix, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
-                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, hipStream_t st) {
-#define GO(Q, V, A) \
-  launch_filter_t<Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, st)
-  if (ix->vec == 16) {
-    if (nqg == 2) { if (nadd == 4) GO(2, 16, 4); else GO(2, 16, 2); }
-    else          { if (nadd == 4) GO(1, 16, 4); else GO(1, 16, 2); }
-  } else {
-    if (nqg == 2) { if (nadd == 4) GO(2, 4, 4); else GO(2, 4, 2); }
-    else          { if (nadd == 4) GO(1, 4, 4); else GO(1, 4, 2); }
-  }
+void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
+                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, int B, hipStream_t st) {
+#define GO(W_, Q, V, A) \
+  launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, B, st)
+#define GO_QV(W_, Q, V) do { if (nadd == 4) GO(W_, Q, V, 4); else GO(W_, Q, V, 2); } while (0)
+#define GO_W(W_) do {                                                  \
+    if (ix->vec == 16) { if (nqg == 2) GO_QV(W_, 2, 16); else GO_QV(W_, 1, 16); } \
+    else               { if (nqg == 2) GO_QV(W_, 2, 4); else GO_QV(W_, 1, 4); }   \
+  } while (0)
+  if (qw == 16) GO_W(16); else if (qw == 8) GO_W(8); else GO_W(4);
+#undef GO_W
+#undef GO_QV
 #undef GO
 }
 
@@ -481,7 +542,7 @@ void launch_filter(gulon_index *ix, int nqg, int nadd, int ftiles, int nchunks, 
 
 bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
   const ScanTuning &t = tuning();
-  return t.filter && ix->w == 4 && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 4096 <= FILTER_LDS_BUDGET &&
+  return t.filter && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 256 * 4 <= FILTER_LDS_BUDGET &&
          rb_total >= t.filter_min_rb && rb_total >= t.filter_period;
 }
 
@@ -489,14 +550,18 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
                       float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
   const ScanTuning &t = tuning();
   const int keff = K + 1;
-  const int QT = 4 * ix->nsub;
+  const int W = ix->w;               // fp32 table interleave of the exact kernels
+  const int QT = W * ix->nsub;
   const int ntiles = ceil_div(B, QT);
   const int Bp = ntiles * QT;
+  const int qw = filter_qw(ix);
   const int nqg = filter_nqg(ix);
-  const int nadd = t.filter_nadd;
+  // entries summed in 8 bits before widening: 4 (6-bit levels) is cheapest, but the bound's slack
+  // grows with m / levels, so wide indexes take 2 (7-bit levels) unless told otherwise
+  const int nadd = t.filter_nadd ? t.filter_nadd : (ix->m_pad <= 16 ? 4 : 2);
   const int qmax = 255 / nadd;
-  const int ftiles = ceil_div(B, 16 * nqg);
-  const int Bq = ftiles * nqg * 16;
+  const int ftiles = ceil_div(B, qw * nqg);
+  const int Bq = ceil_div(ftiles * nqg * qw, 16) * 16;   // whole 16-query quantisation groups
   const int cap = std::max(64, t.filter_cap / NSLOT);   // entries per sub-queue
   const int rb_begin = from / 64;
   const int rb_total = ceil_div(until, 64) - rb_begin;
@@ -528,7 +593,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   ix->fin_v.ensure((size_t)Bq * keff);
   ix->fin_i.ensure((size_t)Bq * keff);
   ix->qmins.ensure((size_t)Bq * ix->m_pad);
-  ix->qtab.ensure((size_t)(Bq / 16) * ix->m_pad * 256 * 16);
+  ix->qtab.ensure((size_t)Bq * ix->m_pad * 256);
   ix->sv_cnt.ensure((size_t)Bq * NSLOT);
   ix->sv_queue.ensure((size_t)Bq * NSLOT * cap);
   ix->fb_tile.ensure((size_t)ntiles);
@@ -537,7 +602,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   HIP_CHECK(hipMemsetAsync(ix->fb_tile.p, 0, sizeof(int) * (size_t)ntiles, st));
   HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Bq * NSLOT, st));
 
-  launch_build_tables(4, ix, dQ, B, Bp, ix->tables.p, st);
+  launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st);
   {   // bounds from a strided sample of about filter_sample rows; resets the running lists
     // sample size ~ sqrt(rows): the sample scan costs ~1.4 us per 1000 rows, the first filter
     // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
@@ -545,22 +610,23 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     int sblocks = std::max(NW, std::min(rb_total, ceil_div(srows, 64)));
     const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
     const int se = rbmap_count(rb_total, smap);
-    const size_t lds_bytes = std::max((size_t)ix->m_pad * 256 * 16, (size_t)4 * NW * 64 * 4);
-#define BS(V)                                                                                                       \
+    const size_t lds_bytes = std::max((size_t)ix->m_pad * 256 * 4 * W, (size_t)W * NW * 64 * 4);
+#define BS(V, W_)                                                                                                   \
     {                                                                                                               \
-      auto kern = bound_scan<V>;                                                                                    \
+      auto kern = bound_scan<V, W_>;                                                                                \
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                   \
-      hipLaunchKernelGGL(kern, dim3(Bp / 4), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,   \
-                         reinterpret_cast<const float4 *>(ix->tables.p), from, until, rb_begin, se, smap, B, keff,  \
-                         ix->tau0.p, ix->fin_v.p, ix->fin_i.p);                                                     \
+      hipLaunchKernelGGL(kern, dim3(Bp / W_), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,  \
+                         ix->tables.p, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p,           \
+                         ix->fin_i.p);                                                                              \
     }
-    if (ix->vec == 16) BS(16) else BS(4)
+    if (ix->vec == 16) { if (W == 4) BS(16, 4) else if (W == 2) BS(16, 2) else BS(16, 1) }
+    else               { if (W == 4) BS(4, 4) else if (W == 2) BS(4, 2) else BS(4, 1) }
 #undef BS
     HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(qt_mins, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
-                     reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, ix->qmins.p);
+  hipLaunchKernelGGL(qt_mins, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st, ix->tables.p, W, Bp, ix->m_pad, ix->k,
+                     ix->qmins.p);
   HIP_CHECK(hipGetLastError());
 
   const bool stats = getenv("GULON_FILTER_STATS") != nullptr;
@@ -570,13 +636,15 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     if (en <= 0) continue;
     int nc = 1, per = 1;
     chunking(en, ftiles, t.filter_blocks, nc, per);
-    hipLaunchKernelGGL(qt_quantize, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st,
-                       reinterpret_cast<const float4 *>(ix->tables.p), Bp, ix->m_pad, ix->k, B, ix->qmins.p,
-                       ix->fin_v.p, ix->fin_i.p, ix->tau0.p, keff, qmax, reinterpret_cast<uint4 *>(ix->qtab.p),
+    hipLaunchKernelGGL(qt_quantize, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st, ix->tables.p, W, Bp, ix->m_pad, ix->k,
+                       B, ix->qmins.p, ix->fin_v.p, ix->fin_i.p, ix->tau0.p, keff, qmax, qw, ix->qtab.p,
                        ix->fb_tile.p, QT);
     HIP_CHECK(hipGetLastError());
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool main_stage = sidx == 2;
+    // a first stage that keeps more than ~3 % of its (query, row) pairs means the bounds do not
+    // separate anything for this query: give up on it before the main stage
+    const int give_up = main_stage ? 0 : std::max(256, (int)std::min<long long>((long long)en * 64 * 3 / 100, 1 << 30));
     const bool timed = ix->profile && main_stage;   // the roofline line is about the main-stage kernel
     if (timed) {
       ev0 = ix->take_event();
@@ -596,7 +664,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
         HIP_CHECK(hipStreamWaitEvent(st, it->second, 0));   // only the main stage takes turns
       }
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
-      launch_filter(ix, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage, st);
+      launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage, B, st);
       if (main_stage) HIP_CHECK(hipEventRecord(it->second, st));
     }
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
@@ -615,12 +683,12 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     }
     if (ix->vec == 16)
       hipLaunchKernelGGL(survivors_kernel<16>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
-                         ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
-                         ix->fb_tile.p, QT);
+                         W, ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
+                         ix->fb_tile.p, QT, give_up);
     else
       hipLaunchKernelGGL(survivors_kernel<4>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
-                         ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
-                         ix->fb_tile.p, QT);
+                         W, ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
+                         ix->fb_tile.p, QT, give_up);
     HIP_CHECK(hipGetLastError());
   }
 

@@ -493,7 +493,7 @@ bool ScanTuning::set(const char *key, int v) {
   else if (k == "GULON_FILTER_PERIOD") { if (v >= 3) filter_period = v; }
   else if (k == "GULON_FILTER_STAGE1") { if (v >= 1) filter_stage1 = v; }
   else if (k == "GULON_FILTER_CAP") { if (v >= 64) filter_cap = v; }
-  else if (k == "GULON_FILTER_NADD") { if (v == 2 || v == 4) filter_nadd = v; }
+  else if (k == "GULON_FILTER_NADD") { if (v == 0 || v == 2 || v == 4) filter_nadd = v; }
   else if (k == "GULON_FILTER_SAMPLE") { if (v >= 1) filter_sample = v; }
   else if (k == "GULON_FILTER_STAGE0") { if (v >= 0) filter_stage0 = v; }
   else if (k == "GULON_FILTER_BLOCKS") { if (v >= 1) filter_blocks = v; }

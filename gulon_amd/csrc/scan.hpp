@@ -93,7 +93,7 @@ struct ScanTuning {
   int filter_stage0 = 0;     // blocks per period scanned by an extra first filter stage (0: none)
   int filter_stage1 = 6;     // blocks per period scanned by the second filter stage
   int filter_cap = 32768;    // survivor queue entries per query and stage
-  int filter_nadd = 4;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels)
+  int filter_nadd = 0;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels, 0: by m)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch
   ScanTuning();
   bool set(const char *key, int v);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_MIN_RB": 512, "GULON_FILTER_PERIOD": 128,
             "GULON_FILTER_STAGE0": 0, "GULON_FILTER_STAGE1": 6, "GULON_FILTER_CAP": 32768,
-            "GULON_FILTER_NADD": 4, "GULON_FILTER_SAMPLE": 65536}
+            "GULON_FILTER_NADD": 0, "GULON_FILTER_SAMPLE": 65536}
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +53,11 @@ def test_tuning_rejects_unknown_key(g):
     (20000, 8, 8, 1, 2, 7, 0, None),                # k = 1: every row has the same distance
     (20000, 16, 4, 3, 4, 63, 0, None),              # width-2 codes, max K
     (50000, 128, 16, 256, 8, 10, 12345, 40001),     # from/until sub-range (partial first and last block)
-    (20000, 72, 36, 256, 5, 10, 0, None),           # widest table the filter takes (m_pad = 36)
+    (20000, 72, 36, 256, 5, 10, 0, None),           # widest 16-queries-per-entry table (m_pad = 36)
+    (30000, 128, 64, 256, 21, 10, 0, None),         # m = 64: 8 queries per entry (ds_read_b64), float2 exact tables
+    (20000, 96, 48, 37, 9, 10, 77, 15000),          # m = 48, k = 37, sub-range
+    (12000, 200, 100, 256, 7, 10, 0, None),         # m = 100: 4 queries per entry (ds_read_b32), scalar exact tables
+    (12000, 80, 40, 256, 35, 3, 0, None),           # m = 40: 8 per entry, several tiles
 ])
 def test_filtered_query_bit_exact(oracle, g, tune, n, d, m, k, B, K, frm, until, nadd):
     tune(GULON_FILTER_NADD=nadd)
