@@ -74,16 +74,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     L = N.lib()
     n, d, m, k, B, K = args.rows, args.dim, args.quantizers, args.clusters, args.batch, args.knn
+    t_origin = time.perf_counter()
+
+    def note(what):     # progress on stderr (GULON_BENCH_VERBOSE=1): long builds are not mistaken for hangs
+        if os.environ.get("GULON_BENCH_VERBOSE") and rank == 0:
+            print(f"[bench +{time.perf_counter() - t_origin:7.2f}s] {what}", file=sys.stderr, flush=True)
 
     # ---- untimed build: synthetic clustered data -> PQ train -> encode (all on the GPU) -----
     t0 = time.perf_counter()
     dm = g.DeviceMatrix.synthetic(n, d, args.data_kind, 1234, 1000)
     t1 = time.perf_counter()
+    note("synthetic data on the device")
     if world == 1:
         pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, args.train_iters))
         t2 = time.perf_counter()
+        note("PQ trained")
         enc = pq.encode(dm)
         t3 = time.perf_counter()
+        note("encoded")
         lo, hi = shard_bounds(n, world, rank)
         shard = local_shard(pq, enc, lo, hi)
     else:
@@ -100,6 +108,7 @@ def main():
     shardeds = [ShardedIndex(e, n, rank, world, dist) for e in engines]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
     engine, sharded, index = engines[0], shardeds[0], engines[0].index
+    note("device index built")
     build_s = dict(synth=t1 - t0, train=t2 - t1, encode=t3 - t2)
 
     # ---- queries: B dataset rows drawn with java.util.Random(0) (Tests.scala:76-87) --------
@@ -126,6 +135,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("first batches done")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -154,6 +164,7 @@ def main():
     filtered = rows_per_launch < 0.999 * nloc
     kernel_name = "filter_kernel" if filtered else "scan_kernel"
 
+    note("timed region done")
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
     alg_bytes = float(B) * rows_per_launch * m            # m code bytes per (query, row) pair
@@ -195,6 +206,7 @@ def main():
             result["recall_sd"] = sd
             result["recall_seconds"] = time.perf_counter() - t
             result["tie_flagged_queries"] = int((res_flg != 0).sum())
+            note("recall done")
         if world == 1 and enc is not None and not args.no_cpu_baseline:
             from oracle import oracle                      # CPU baseline leg only (the checker, timed)
             codes_h = np.stack(enc.encodings) if coder.width == 8 else None

@@ -35,9 +35,10 @@ __device__ static inline float synth_gauss(uint64_t seed, uint64_t stream, uint6
   }
   return acc - 6.0f;
 }
+// grid-stride: a dispatch cannot carry 2^32 or more work-items, and n * d can (10 M x 1024)
 __global__ void synth_fill(float *__restrict__ X, long long total, int d, int kind, uint64_t seed, int ncentres) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
   uint64_t idx = (uint64_t)t;
   uint64_t row = idx / (uint64_t)d;
   uint64_t c = idx - row * (uint64_t)d;
@@ -59,6 +60,7 @@ __global__ void synth_fill(float *__restrict__ X, long long total, int d, int ki
     v = centre + g * scale;
   }
   X[t] = v;
+  }
 }
 
 __global__ void gather_rows(const float *__restrict__ X, int d, const int *__restrict__ rows, long long total,
@@ -238,7 +240,8 @@ GULON_API int32_t gulon_dataset_create_synth(int32_t n, int32_t d, int32_t kind,
     long long total = (long long)n * d;
     ds->x.alloc(std::max<size_t>((size_t)total, 1));
     if (total) {
-      hipLaunchKernelGGL(synth_fill, dim3(ceil_div(total, 256)), dim3(256), 0, 0, ds->x.p, total, d, kind, seed,
+      hipLaunchKernelGGL(synth_fill, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1 << 20)), dim3(256), 0, 0,
+                         ds->x.p, total, d, kind, seed,
                          ncentres);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipDeviceSynchronize());

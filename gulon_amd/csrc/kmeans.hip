@@ -708,6 +708,8 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     pr.use_mfma = mfma_assign_supported(s, k);
     if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, pr.st);
     pr.xs.alloc((size_t)n * s);
+    GULON_UNSUPPORTED((long long)n * s >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items",
+                      (long long)n * s);
     hipLaunchKernelGGL(copy_slice, dim3(ceil_div((long long)n * s, 256)), dim3(256), 0, pr.st, dX, ld, from[p], s,
                        (long long)n * s, pr.xs.p);
     make_job(p, pr.c_prev.p, pr.a_prev.p);
@@ -743,6 +745,12 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     lap("  assign stage1");
     finish_assigns(act);
     lap("  assign stages 2-3");
+    if (trace) {
+      unsigned long long fl = 0, dr = 0;
+      for (int p : act) { fl += P[p].ws.last_flagged; dr += P[p].ws.last_draws; }
+      fprintf(stderr, "[gulon trace]   rows re-checked exactly %llu of %llu (%.3g), tie draws %llu\n", fl,
+              (unsigned long long)n * act.size(), (double)fl / ((double)n * act.size()), dr);
+    }
     std::vector<unsigned> h_mism(np, 0);
     for (int p : act) {
       Prob &pr = P[p];

@@ -212,6 +212,7 @@ void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps
   ntile = (ntile + 1) / 2 * 2;   // whole pairs
   long long total = ntile * ps.T * 64;
   ps.xq.ensure((size_t)std::max<long long>(total, 1));
+  GULON_UNSUPPORTED(total >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items", total);
   if (total)
     hipLaunchKernelGGL(pack_slice_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dX, n, ld, from, s, ps.T,
                        total, ps.xq.p);
