@@ -317,8 +317,11 @@ __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngrou
   }
 }
 
-// each wave places its chunk's rows in order: order[start[c] + rank] = row (stable)
-__global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k) {
+// each wave places its chunk's rows in order: order[start[c] + rank] = row (stable).
+// The lanes holding the same cluster are found without a loop: one ballot per key bit, and the
+// AND of (bit set ? ballot : ~ballot) over the bits is the mask of lanes with an equal key; the
+// rank inside the cluster is the population count of that mask below the lane.
+__global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits) {
   const UpdDesc D = descs[blockIdx.y];
   extern __shared__ unsigned sh[];  // 4 * k running positions
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -331,20 +334,22 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
   for (int c = lane; c < k; c += 64)
     run[c] = D.start[c] + D.gtot[(size_t)grp * k + c] + D.hist[(size_t)chunk * k + c];
   const unsigned long long lt = (1ull << lane) - 1ull;
+  int key_next = r0 + lane < r1 ? D.assign[r0 + lane] : 0;
   for (long long base = r0; base < r1; base += 64) {
-    long long r = base + lane;
-    bool valid = r < r1;
-    int key = valid ? D.assign[r] : -1;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-      int l = __ffsll((long long)todo) - 1;
-      int k0 = __builtin_amdgcn_readlane(key, l);
-      unsigned long long mk = __ballot(valid && key == k0);
-      unsigned b = run[k0];                      // wave-uniform read
-      if (valid && key == k0) D.order[b + __popcll(mk & lt)] = (int)r;
-      if (lane == l) run[k0] = b + __popcll(mk);
-      todo &= ~mk;
+    const long long r = base + lane;
+    const bool valid = r < r1;
+    const int key = key_next;
+    if (base + 64 + lane < r1) key_next = D.assign[base + 64 + lane];
+    unsigned long long same = __ballot(valid);
+    for (int bit = 0; bit < key_bits; bit++) {
+      const unsigned long long bm = __ballot((key >> bit) & 1);
+      same &= ((key >> bit) & 1) ? bm : ~bm;
     }
+    // same-wave LDS accesses execute in program order: every lane of a cluster reads the
+    // running position before the cluster's first lane advances it
+    const unsigned b = valid ? run[key] : 0u;
+    if (valid) D.order[b + __popcll(same & lt)] = (int)r;
+    if (valid && (same & lt) == 0ull) run[key] = b + __popcll(same);
   }
 }
 
@@ -567,7 +572,9 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
   hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256), np), dim3(256), 0, st, d_descs,
                      nchunks, k);
   hipLaunchKernelGGL(sort_scan_top, dim3(1, np), dim3(256), sizeof(unsigned) * (size_t)k, st, d_descs, ngroups, k);
-  hipLaunchKernelGGL(sort_place, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k);
+  int key_bits = 0;
+  while ((1 << key_bits) < k) key_bits++;
+  hipLaunchKernelGGL(sort_place, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k, key_bits);
   hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * smax, 64), np), dim3(64), 0, st, d_descs, k);
   HIP_CHECK(hipGetLastError());
 }
