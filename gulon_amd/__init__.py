@@ -3,6 +3,7 @@ Index / ProductQuantizer / KMeans API (host mirror over libgulon_hip.so)."""
 from . import native
 from .coder import Coder, width_for_clusters
 from .index import Index, PQIndex, Result, SortedIndex, exact_nearest_neighbours, prepare_query
+from .grouped import GroupedIndex, GroupedVectors, LimitGroups, LimitVectors, group
 from .kmeans import KMeans
 from .kmeans import Config as KMeansConfig
 from .matrix import DeviceMatrix, Matrix
@@ -10,7 +11,7 @@ from .product_quantizer import EncodedMatrix, ProductQuantizer, Quantizer
 from .product_quantizer import Config as ProductQuantizerConfig
 from .vectors import Vectors, subvector_bounds, subvectors
 
-__all__ = ["native", "Coder", "width_for_clusters", "Index", "PQIndex", "Result", "SortedIndex",
+__all__ = ["native", "GroupedIndex", "GroupedVectors", "LimitGroups", "LimitVectors", "group", "Coder", "width_for_clusters", "Index", "PQIndex", "Result", "SortedIndex",
            "exact_nearest_neighbours", "prepare_query", "KMeans", "KMeansConfig", "DeviceMatrix", "Matrix",
            "EncodedMatrix", "ProductQuantizer", "Quantizer", "ProductQuantizerConfig", "Vectors",
            "subvector_bounds", "subvectors"]

@@ -1,0 +1,437 @@
+// GroupedIndex (Index.scala:231-308): coarse groups + product-quantized residuals.
+//
+//   query(k, q):  nn = searchSpace(q)                       nearest coarse centroids (TopKHeap + deleteAll)
+//                 for c in nn:  residual = q - centroid(c)   MathUtils.subtract
+//                               heap.merge(vectorIndex.query(k, residual, from(c), until(c)))
+//                 Result.fromHeap(heap)
+//
+// The per-group heaps are merged with TopKHeap.merge, i.e. update() of the other heap's slots in
+// ARRAY order, so under distance ties the answer depends on the literal heaps.  Groups are short
+// (n / #groups rows), so the GPU path simply runs the reference's algorithm literally:
+//   gq_coarse       one wave per query: centroid distances 64 at a time, literal TopKHeap in
+//                   registers (lane = slot) for LimitGroups; (distance, id) sort for LimitVectors
+//   gq_group_scan   one wave per (query, searched group): the residual's m x k table is built in
+//                   LDS (Index.prepareQuery arithmetic), the group's rows are scored 64 at a time
+//                   (PQIndex.distances order) and pushed, in row order, through a literal TopKHeap;
+//                   the heap is stored in array order
+//   gq_merge        one wave per query: TopKHeap.merge of the group heaps in search order, then
+//                   Result.fromHeap
+// No tie flags and no replay are needed here: the literal heaps ARE the reference semantics.
+#include "scan.hpp"
+
+using gulon::DevBuf;
+
+struct gulon_grouped_index {
+  gulon_index *pq = nullptr;       // residual codes + residual codebooks (row-blocked layout of scan.hip)
+  int32_t n = 0, d = 0, g = 0;
+  DevBuf<float> gcent;             // [g][d] centroids of the non-empty groups
+  DevBuf<int> bounds;              // [g+1] first row of every group, then n
+  // scratch (grown on demand under mu)
+  DevBuf<float> q_dev, cdist, hv, od;
+  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc;
+  std::mutex mu;
+  ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
+};
+
+namespace gulon {
+namespace {
+
+// TopKHeap.scala with lane = slot storage (K <= 63); every index is wave-uniform.
+struct RegHeap {
+  float v = 0.f;
+  int k = 0;
+  int size = 0;
+  int cap;
+  int lane;
+  __device__ RegHeap(int cap_, int lane_) : cap(cap_), lane(lane_) {}
+  __device__ float val(int i) const { return readlane_f(v, i); }
+  __device__ int key(int i) const { return readlane_i(k, i); }
+  __device__ void swp(int a, int b) {
+    const float va = val(a), vb = val(b);
+    const int ka = key(a), kb = key(b);
+    if (lane == a) { v = vb; k = kb; }
+    if (lane == b) { v = va; k = ka; }
+  }
+  __device__ void down(int i) {                             // percolateDown, TopKHeap.scala:30-42
+    for (;;) {
+      int top = i;
+      const int lc = 2 * i + 1, rc = 2 * i + 2;
+      if (lc < size && val(top) < val(lc)) top = lc;
+      if (rc < size && val(top) < val(rc)) top = rc;
+      if (top == i) break;
+      swp(i, top);
+      i = top;
+    }
+  }
+  __device__ int del() {                                    // delete, TopKHeap.scala:57-67
+    size -= 1;
+    const int removed = key(0);
+    const float lv = val(size);
+    const int lk = key(size);
+    if (lane == 0) { v = lv; k = lk; }
+    down(0);
+    return removed;
+  }
+  __device__ bool would_insert(float x) const { return size < cap || val(0) > x; }
+  __device__ void update(int kk, float x) {                 // update, TopKHeap.scala:69-79
+    if (size == cap && val(0) > x) del();
+    if (size < cap) {
+      if (lane == size) { v = x; k = kk; }
+      int i = size;
+      while (i > 0) {                                       // percolateUp, TopKHeap.scala:21-28
+        const int p = (i - 1) / 2;
+        if (val(i) > val(p)) { swp(i, p); i = p; } else break;
+      }
+      size += 1;
+    }
+  }
+};
+
+// ---- coarse search: distances of every query to every group centroid -------------------------
+// MathUtils.distanceSq(centroid, query): sum of (q_e - c_e)^2, e ascending, unfused.
+__global__ __launch_bounds__(256) void gq_cdist(const float *__restrict__ gcent, int g, int d,
+                                                const float *__restrict__ Q, int B, float *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * g) return;
+  const int q = (int)(t / g), c = (int)(t - (long long)q * g);
+  const float *x = gcent + (size_t)c * d, *y = Q + (size_t)q * d;
+  float sum = 0.f;
+  for (int e = 0; e < d; e++) {
+    const float dx = y[e] - x[e];
+    sum += dx * dx;
+  }
+  out[t] = sum;
+}
+
+// LimitGroups(limit <= 63): literal exactNearestNeighbours(centroids, query, limit).deleteAll()
+__global__ __launch_bounds__(64) void gq_nearest_groups(const float *__restrict__ cdist, int g, int limit,
+                                                        int *__restrict__ nn /*[B][stride]*/, int stride,
+                                                        int *__restrict__ nn_cnt) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  RegHeap h(limit, lane);
+  const float *dq = cdist + (size_t)q * g;
+  for (int base = 0; base < g; base += 64) {
+    const bool have = base + lane < g;
+    const float dv = have ? dq[base + lane] : 0.f;
+    // centroids in index order through heap.update; the ballot only skips those the heap would reject
+    unsigned long long mk = __ballot(have && h.would_insert(dv));
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float x = readlane_f(dv, l);
+      if (h.would_insert(x)) h.update(base + l, x);
+    }
+  }
+  const int live = h.size;
+  for (int i = live - 1; i >= 0; i--) {                      // deleteAll(): fill from the back
+    const int kk = h.del();
+    if (lane == 0) nn[(size_t)q * stride + i] = kk;
+  }
+  if (lane == 0) nn_cnt[q] = live;
+}
+
+// LimitVectors(limit) (and LimitGroups beyond 63): all centroids in ascending (distance, id)
+// order -- the reference's heap order wherever no two centroid distances are equal -- cut after
+// enough groups to cover `limit` rows (or after `limit` groups).  One workgroup per query, bitonic
+// sort in LDS.
+__global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict__ cdist, int g, int n2,
+                                                        const int *__restrict__ bounds, int by_vectors, int limit,
+                                                        int *__restrict__ nn, int stride, int *__restrict__ nn_cnt) {
+  extern __shared__ float gs_lds[];
+  float *sv = gs_lds;
+  int *si = reinterpret_cast<int *>(gs_lds + n2);
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < n2; e += 256) {
+    float v = e < g ? cdist[(size_t)q * g + e] : INFINITY;
+    sv[e] = v != v ? INFINITY : v;    // NaN distances order last
+    si[e] = e < g ? e : INT_MAX;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      for (int i = tid; i < n2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float a = sv[i], b = sv[l];
+          const int ai = si[i], bi = si[l];
+          const bool gt = a > b || (a == b && ai > bi);
+          if (gt == ((i & k) == 0)) { sv[i] = b; sv[l] = a; si[i] = bi; si[l] = ai; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    int i = 0;
+    if (by_vectors) {
+      int count = 0;
+      while (i < g && count < limit) { const int c = si[i]; count += bounds[c + 1] - bounds[c]; i++; }
+    } else {
+      i = min(limit, g);
+    }
+    nn_cnt[q] = i;
+  }
+  __syncthreads();
+  const int cnt = nn_cnt[q];
+  for (int e = tid; e < cnt; e += 256) nn[(size_t)q * stride + e] = si[e];
+}
+
+// ---- one searched group of one query -------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(64) void gq_group_scan(const uint8_t *__restrict__ codes, int ng, int m, int m_pad, int k,
+                                                    int d, const float *__restrict__ pq_cents,
+                                                    const int *__restrict__ from, const int *__restrict__ sdim,
+                                                    const float *__restrict__ gcent, const int *__restrict__ bounds,
+                                                    const float *__restrict__ Q, const int *__restrict__ nn,
+                                                    int nn_stride, const int *__restrict__ nn_cnt, int stride, int K,
+                                                    int *__restrict__ hk, float *__restrict__ hv,
+                                                    int *__restrict__ hs) {
+  using Word = typename CodeWord<VEC>::type;
+  extern __shared__ float gtab[];   // m_pad * 256 table entries, then the d residual components
+  const int q = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  if (t >= nn_cnt[q]) return;
+  const int c = nn[(size_t)q * nn_stride + t];
+  float *res = gtab + m_pad * 256;
+  for (int e = lane; e < d; e += 64) res[e] = Q[(size_t)q * d + e] - gcent[(size_t)c * d + e];   // MathUtils.subtract
+  __syncthreads();
+  // Index.prepareQuery on the residual: T[j][c'] = sum_e (r[from_j+e] - cent_j[c'][e])^2, e ascending, unfused
+  for (int e = lane; e < m_pad * 256; e += 64) {
+    const int j = e >> 8, cc = e & 255;
+    float acc = 0.f;
+    if (j < m && cc < k) {
+      const int fr = from[j], s = sdim[j];
+      const float *cent = pq_cents + (size_t)k * fr + (size_t)cc * s;
+      for (int x = 0; x < s; x++) {
+        const float dd = res[fr + x] - cent[x];
+        acc += dd * dd;
+      }
+    }
+    gtab[e] = acc;
+  }
+  __syncthreads();
+  const int row_from = bounds[c], row_until = bounds[c + 1];
+  RegHeap h(K, lane);
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  for (int rb = row_from / 64; rb * 64 < row_until; rb++) {
+    float acc = 0.f;                 // PQIndex.distances: j ascending, unfused fp32
+    for (int gi = 0; gi < ng; gi++) {
+      const Word w = cw[((size_t)rb * ng + gi) * 64 + lane];
+      const float *tj = gtab + gi * VEC * 256;
+#pragma unroll
+      for (int b = 0; b < VEC; b++) acc += tj[b * 256 + code_byte<VEC>(w, b)];
+    }
+    const int row = rb * 64 + lane;
+    const bool valid = row >= row_from && row < row_until;
+    // rows in ascending order through heap.update; the ballot only skips rows the heap would
+    // reject anyway (full and root <= value -- NaN compares false and is rejected like there)
+    unsigned long long mk = __ballot(valid && (h.size < K || h.val(0) > acc));
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float x = readlane_f(acc, l);
+      if (h.would_insert(x)) h.update(rb * 64 + l, x);
+    }
+  }
+  const size_t o = ((size_t)q * stride + t) * K;
+  if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
+  if (lane == 0) hs[(size_t)q * stride + t] = h.size;
+}
+
+// ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
+__global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
+                                               const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
+                                               int K, int *__restrict__ out_idx, float *__restrict__ out_dist,
+                                               int *__restrict__ out_count) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  RegHeap h(K, lane);
+  const int cnt = nn_cnt[q];
+  for (int t = 0; t < cnt; t++) {
+    const size_t o = ((size_t)q * stride + t) * K;
+    const int sz = hs[(size_t)q * stride + t];
+    const int kk = lane < sz ? hk[o + lane] : 0;
+    const float vv = lane < sz ? hv[o + lane] : 0.f;
+    for (int i = 0; i < sz; i++) h.update(readlane_i(kk, i), readlane_f(vv, i));   // array order
+  }
+  const int live = h.size;
+  for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
+    const float tv = h.val(0);
+    const int tk = h.del();
+    if (lane == 0) { out_idx[(size_t)q * K + i] = tk; out_dist[(size_t)q * K + i] = tv; }
+  }
+  if (lane >= live && lane < K) { out_idx[(size_t)q * K + lane] = -1; out_dist[(size_t)q * K + lane] = INFINITY; }
+  if (lane == 0 && out_count) out_count[q] = live;
+}
+
+// residual dataset in grouped order: out[i] = X[perm[i]] - gcent[group_of[i]]
+__global__ void gq_residuals(const float *__restrict__ X, int d, const int *__restrict__ perm,
+                             const int *__restrict__ group_of, const float *__restrict__ gcent, long long total,
+                             float *__restrict__ out) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long i = t / d;
+    const int e = (int)(t - i * d);
+    out[t] = X[(size_t)perm[i] * d + e] - gcent[(size_t)group_of[i] * d + e];
+  }
+}
+
+void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, int strategy, int limit, int *d_oi,
+                       float *d_od, int *d_oc, hipStream_t st) {
+  GULON_REQUIRE(B >= 0 && K >= 0, "k and batch size must be non-negative");
+  GULON_REQUIRE(strategy == 0 || strategy == 1, "strategy must be 0 (LimitGroups) or 1 (LimitVectors)");
+  GULON_REQUIRE(limit >= 0, "limit must be non-negative");
+  GULON_UNSUPPORTED(K > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is not supported by the grouped index", K,
+                    GULON_MAX_K);
+  if (B == 0) return;
+  gulon_index *ix = gx->pq;
+  const int g = gx->g;
+  if (K == 0) {
+    if (d_oc) HIP_CHECK(hipMemsetAsync(d_oc, 0, sizeof(int) * (size_t)B, st));
+    return;
+  }
+  // groups searched per query: at most `nn_stride` (LimitVectors: every group holds >= 1 row)
+  const int nn_stride = std::max(1, std::min(limit, g));
+  int stride = nn_stride;
+  gx->cdist.ensure((size_t)B * g);
+  gx->nn.ensure((size_t)B * nn_stride);
+  gx->nn_cnt.ensure((size_t)B);
+  hipLaunchKernelGGL(gq_cdist, dim3(ceil_div((long long)B * g, 256)), dim3(256), 0, st, gx->gcent.p, g, gx->d, dQ, B,
+                     gx->cdist.p);
+  if (strategy == 0 && limit <= GULON_MAX_K && limit >= 1) {
+    hipLaunchKernelGGL(gq_nearest_groups, dim3(B), dim3(64), 0, st, gx->cdist.p, g, limit, gx->nn.p, nn_stride,
+                       gx->nn_cnt.p);
+  } else {
+    int n2 = 64;
+    while (n2 < g) n2 <<= 1;
+    const size_t lds = (size_t)n2 * 8;
+    GULON_UNSUPPORTED(lds > 144 * 1024, "%d groups: ordering all of them needs %zu B of LDS (> 144 KiB)", g, lds);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_sorted_groups),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gq_sorted_groups, dim3(B), dim3(256), lds, st, gx->cdist.p, g, n2, gx->bounds.p, strategy == 1,
+                       limit, gx->nn.p, nn_stride, gx->nn_cnt.p);
+    if (strategy == 1 && nn_stride > 64) {
+      // LimitVectors rarely needs more than a handful of groups: size the per-group heaps by the
+      // largest count of this batch (one small read-back) instead of by the worst case
+      std::vector<int> h((size_t)B);
+      HIP_CHECK(hipMemcpyAsync(h.data(), gx->nn_cnt.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      int mx = 1;
+      for (int v : h) mx = std::max(mx, v);
+      stride = mx;
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+  gx->hk.ensure((size_t)B * stride * K);
+  gx->hv.ensure((size_t)B * stride * K);
+  gx->hs.ensure((size_t)B * stride);
+  const size_t lds = ((size_t)ix->m_pad * 256 + ix->d) * sizeof(float);
+#define GS(V)                                                                                                      \
+  {                                                                                                                \
+    auto kern = gq_group_scan<V>;                                                                                  \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds));                                                                      \
+    hipLaunchKernelGGL(kern, dim3(stride, B), dim3(64), lds, st, ix->codes.p, ix->ng, ix->m, ix->m_pad, ix->k, ix->d, \
+                       ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride,    \
+                       gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p);                                             \
+  }
+  if (ix->vec == 16) GS(16) else GS(4)
+#undef GS
+  hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+                     d_od, d_oc);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+}  // namespace gulon
+
+using namespace gulon;
+
+GULON_API int32_t gulon_dataset_group_residuals(const gulon_dataset *ds, const int32_t *perm,
+                                                const int32_t *group_of, const float *group_centroids, int32_t g,
+                                                gulon_dataset **out) {
+  return guarded([&] {
+    GULON_REQUIRE(ds != nullptr && out != nullptr && (ds->n == 0 || (perm && group_of)) && group_centroids && g >= 1,
+                  "bad arguments");
+    *out = nullptr;
+    const int n = ds->n, d = ds->d;
+    for (int i = 0; i < n; i++) {
+      GULON_REQUIRE(perm[i] >= 0 && perm[i] < n, "perm[%d] = %d out of range", i, perm[i]);
+      GULON_REQUIRE(group_of[i] >= 0 && group_of[i] < g, "group_of[%d] = %d out of range", i, group_of[i]);
+    }
+    std::unique_ptr<gulon_dataset> r(new gulon_dataset());
+    r->n = n; r->d = d;
+    const long long total = (long long)n * d;
+    r->x.alloc(std::max<size_t>((size_t)total, 1));
+    if (total) {
+      DevBuf<int> dp, dg;
+      DevBuf<float> dc;
+      dp.upload(perm, n); dg.upload(group_of, n); dc.upload(group_centroids, (size_t)g * d);
+      hipLaunchKernelGGL(gq_residuals, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1 << 20)), dim3(256), 0,
+                         0, ds->x.p, d, dp.p, dg.p, dc.p, total, r->x.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+    *out = r.release();
+  });
+}
+
+GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
+                                             const float *pq_cents, const float *group_centroids,
+                                             const int32_t *offsets, int32_t g, gulon_grouped_index **out) {
+  return guarded([&] {
+    GULON_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    GULON_REQUIRE(g >= 1 && group_centroids != nullptr && (g == 1 || offsets != nullptr), "bad grouping");
+    // GroupedIndex asserts centroids.length == offsets.length + 1 (Index.scala:240-241); offsets ascend
+    std::vector<int> bounds((size_t)g + 1);
+    bounds[0] = 0;
+    for (int c = 1; c < g; c++) {
+      GULON_REQUIRE(offsets[c - 1] >= bounds[c - 1] && offsets[c - 1] <= n, "group offsets must ascend within [0, n]");
+      bounds[c] = offsets[c - 1];
+    }
+    bounds[g] = n;
+    std::unique_ptr<gulon_grouped_index> gx(new gulon_grouped_index());
+    gulon_index *pq = nullptr;
+    int32_t rc = gulon_index_create(codes, n, d, m, k, pq_cents, 0, &pq);
+    if (rc != GULON_OK) throw DeviceError{rc};
+    gx->pq = pq;
+    gx->n = n; gx->d = d; gx->g = g;
+    gx->gcent.upload(group_centroids, (size_t)g * d);
+    gx->bounds.upload(bounds.data(), bounds.size());
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = gx.release();
+  });
+}
+
+GULON_API int32_t gulon_grouped_index_destroy(gulon_grouped_index *idx) {
+  return guarded([&] { delete idx; });
+}
+
+GULON_API int32_t gulon_grouped_index_batch_query_dev(gulon_grouped_index *idx, const float *d_queries, int32_t b,
+                                                      int32_t k_nn, int32_t strategy, int32_t limit,
+                                                      int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
+                                                      void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    run_grouped_query(idx, d_queries, b, k_nn, strategy, limit, d_out_idx, d_out_dist, d_out_count,
+                      (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_grouped_index_batch_query(gulon_grouped_index *idx, const float *queries, int32_t b,
+                                                  int32_t k_nn, int32_t strategy, int32_t limit, int32_t *out_idx,
+                                                  float *out_dist, int32_t *out_count) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    GULON_REQUIRE(b >= 0 && k_nn >= 0, "k and batch size must be non-negative");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const size_t bk = (size_t)b * (size_t)k_nn;
+    idx->q_dev.ensure((size_t)b * idx->d + 1);
+    idx->oi.ensure(bk + 1); idx->od.ensure(bk + 1); idx->oc.ensure((size_t)b + 1);
+    hipStream_t st = nullptr;
+    if (b > 0) HIP_CHECK(hipMemcpyAsync(idx->q_dev.p, queries, sizeof(float) * (size_t)b * idx->d, hipMemcpyHostToDevice, st));
+    run_grouped_query(idx, idx->q_dev.p, b, k_nn, strategy, limit, idx->oi.p, idx->od.p, idx->oc.p, st);
+    if (bk) { idx->oi.download(out_idx, bk, st); idx->od.download(out_dist, bk, st); }
+    if (b > 0 && out_count) idx->oc.download(out_count, b, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}

@@ -162,3 +162,9 @@ class Index:
         """Index.sorted (Index.scala:107-114): encode, then wrap."""
         encoded = quantizer.encode(as_device(vectors))
         return SortedIndex(PQIndex(quantizer, encoded), metric)
+
+    @staticmethod
+    def grouped(grouped_vectors, residuals_quantizer: ProductQuantizer, strategy, metric="l2"):
+        """Index.grouped (Index.scala:133-147): the quantizer is one on the RESIDUALS."""
+        from .grouped import grouped
+        return grouped(grouped_vectors, residuals_quantizer, strategy, metric)

@@ -84,6 +84,11 @@ SIGNATURES = {
     "gulon_topk_merge_dev": (_i32, [_vp, _vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_profile": (_i32, [_vp, _i32]),
     "gulon_index_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "gulon_dataset_group_residuals": (_i32, [_vp, _i32p, _i32p, _f32p, _i32, C.POINTER(_vp)]),
+    "gulon_grouped_index_create": (_i32, [_u8p, _i32, _i32, _i32, _i32, _f32p, _f32p, _i32p, _i32, C.POINTER(_vp)]),
+    "gulon_grouped_index_destroy": (_i32, [_vp]),
+    "gulon_grouped_index_batch_query": (_i32, [_vp, _f32p, _i32, _i32, _i32, _i32, _i32p, _f32p, _i32p]),
+    "gulon_grouped_index_batch_query_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gulon_replay_pack_words": (C.c_int64, []),
     "gulon_index_replay_collect_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gulon_replay_apply_dev": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -201,6 +201,36 @@ int32_t gulon_index_replay_collect_dev(gulon_index *idx, const float *d_queries,
                                        void *stream);
 int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t b, int32_t k_nn, int32_t *d_out_idx,
                                float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+/* ---- GroupedIndex (Index.scala:231-308): coarse groups + product-quantized residuals ---------
+ * Rows are in GROUPED order (WordVectors.grouped, WordVectors.scala:24-58): stably ordered by the
+ * coarse cluster they were assigned to; group c covers rows [offsets[c-1], offsets[c]) (first group
+ * from 0, last to n); group_centroids holds the centroids of the g NON-EMPTY clusters, in cluster
+ * order; the codes are the ProductQuantizer codes of the RESIDUALS (row - its group's centroid,
+ * WordVectors.Grouped.residuals :118-138).  Returned ids are grouped row positions.
+ *
+ * gulon_dataset_group_residuals builds that residual matrix on the device:
+ *   out[i] = ds[perm[i]] - group_centroids[group_of[i]]                       (MathUtils.subtract)
+ * gulon_grouped_index_batch_query = GroupedIndex.batchQuery (:254-282): per query searchSpace
+ * (:285-299; strategy 0 = LimitGroups(limit), 1 = LimitVectors(limit)), then for every searched
+ * group, nearest first, PQIndex.query on (query - centroid) over the group's rows and
+ * TopKHeap.merge into the result heap, then Result.fromHeap.  The heaps are the reference's,
+ * literally (array order included), so ids and order equal the JVM's also under distance ties;
+ * only the ORDER of equally distant coarse centroids under LimitVectors (or LimitGroups > 63)
+ * follows (distance, id) instead of the heap's.  k_nn <= GULON_MAX_K. */
+typedef struct gulon_grouped_index gulon_grouped_index;
+int32_t gulon_dataset_group_residuals(const gulon_dataset *ds, const int32_t *perm, const int32_t *group_of,
+                                      const float *group_centroids, int32_t g, gulon_dataset **out);
+int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
+                                   const float *pq_cents, const float *group_centroids, const int32_t *offsets,
+                                   int32_t g, gulon_grouped_index **out);
+int32_t gulon_grouped_index_destroy(gulon_grouped_index *idx);
+int32_t gulon_grouped_index_batch_query(gulon_grouped_index *idx, const float *queries, int32_t b, int32_t k_nn,
+                                        int32_t strategy, int32_t limit, int32_t *out_idx, float *out_dist,
+                                        int32_t *out_count);
+int32_t gulon_grouped_index_batch_query_dev(gulon_grouped_index *idx, const float *d_queries, int32_t b,
+                                            int32_t k_nn, int32_t strategy, int32_t limit, int32_t *d_out_idx,
+                                            float *d_out_dist, int32_t *d_out_count, void *stream);
+
 /* Kernel timing for the roofline line of bench.py: when enabled, every scan-kernel
  * launch of this index is bracketed by hipEvents on the launch stream;
  * gulon_index_profile_read synchronises them and returns the summed duration. */

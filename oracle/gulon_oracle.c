@@ -608,6 +608,73 @@ GO_API int32_t go_exact_knn(const float *X, int32_t n, int32_t d, int32_t from_r
   return 0;
 }
 
+/* GroupedIndex.query (Index.scala:265-282) + searchSpace (:285-299) + getBounds (:259-263)
+ * for B queries (batchQuery = one query at a time, :254-257).
+ *   idx      residual PQ codes [m][n], rows in grouped order (WordVectors.grouped, :24-58)
+ *   gcent    the g non-empty coarse centroids [g][d], offsets[g-1] = first row of groups 1..g-1
+ *   strategy 0 = LimitGroups(limit), 1 = LimitVectors(limit)
+ * Every searched group gets its own TopKHeap from PQIndex.query on the residual
+ * (query - centroid, MathUtils.subtract :74-83); the heaps are folded into the result with
+ * TopKHeap.merge (:44-53), i.e. update() of the other heap's slots in ARRAY order. */
+GO_API int32_t go_grouped_query(const int32_t *idx, int32_t n, int32_t d, int32_t m, int32_t k,
+                                const float *pq_cents, const float *gcent, const int32_t *offsets, int32_t g,
+                                const float *Q, int32_t B, int32_t K, int32_t strategy, int32_t limit,
+                                int32_t *out_idx, float *out_dist, int32_t *out_count) {
+  if (g < 1 || limit < 0) return -1;
+  float *T = (float *)malloc(sizeof(float) * (size_t)m * k + 4);
+  float *ds = (float *)malloc(sizeof(float) * 4096);
+  float *res = (float *)malloc(sizeof(float) * (size_t)d);
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)g);
+  float *odist = (float *)malloc(sizeof(float) * (size_t)g);
+  for (int32_t q = 0; q < B; q++) {
+    const float *query = Q + (size_t)q * d;
+    /* searchSpace */
+    int32_t hk = strategy == 0 ? limit : g;
+    go_heap *hc = go_heap_new(hk);
+    for (int32_t i = 0; i < g; i++) go_heap_update(hc, i, go_distance_sq(gcent + (size_t)i * d, query, d));
+    int32_t nn = go_heap_drain(hc, order, odist);          /* deleteAll(): ascending by distance */
+    go_heap_free(hc);
+    if (strategy == 1) {
+      int32_t i = 0, count = 0;
+      while (i < nn && count < limit) {
+        int32_t c = order[i];
+        int32_t start = c == 0 ? 0 : offsets[c - 1];
+        int32_t end = c == g - 1 ? n : offsets[c];
+        count += end - start;
+        i++;
+      }
+      nn = i;
+    }
+    go_heap *heap = go_heap_new(K);
+    for (int32_t t = 0; t < nn; t++) {
+      int32_t c = order[t];
+      int32_t from_row = c == 0 ? 0 : offsets[c - 1];
+      int32_t until_row = c == g - 1 ? n : offsets[c];
+      for (int32_t e = 0; e < d; e++) res[e] = query[e] - gcent[(size_t)c * d + e];
+      go_prepare_query(pq_cents, d, m, k, res, 1, T);
+      go_heap *hg = go_heap_new(K);
+      for (int32_t i = from_row; i < until_row;) {
+        int32_t bs = until_row - i < 4096 ? until_row - i : 4096;
+        memset(ds, 0, sizeof(float) * bs);
+        for (int32_t j = 0; j < m; j++) {
+          const float *qds = T + (size_t)j * k;
+          const int32_t *code = idx + (size_t)j * n + i;
+          for (int32_t r = 0; r < bs; r++) ds[r] += qds[code[r]];
+        }
+        for (int32_t r = 0; r < bs; r++) go_heap_update(hg, i + r, ds[r]);
+        i += bs;
+      }
+      go_heap_merge(heap, hg);
+      go_heap_free(hg);
+    }
+    int32_t cnt = go_heap_drain(heap, out_idx + (size_t)q * K, out_dist + (size_t)q * K);
+    if (out_count) out_count[q] = cnt;
+    go_heap_free(heap);
+  }
+  free(odist); free(order); free(res); free(ds); free(T);
+  return 0;
+}
+
 /* Tests.recallOf (Tests.scala:18-41) for ONE k (eps = 0): fraction of the
  * first K returned rows whose exact distanceSq(query, X[row]) <= cutoff,
  * cutoff = exact K-th neighbour distance.  Returns mean recall; *sd_out the

@@ -57,6 +57,9 @@ def lib():
         L.go_distance_sq.argtypes = [_f32p, _f32p, C.c_int32]
         L.go_distance_sq.restype = C.c_float
         L.go_normalize.argtypes = [_f32p, C.c_int32, _f32p]
+        L.go_grouped_query.argtypes = [_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, _i32p, C.c_int32,
+                                       _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]
+        L.go_grouped_query.restype = C.c_int32
         L.go_heap_new.argtypes = [C.c_int32]
         L.go_heap_new.restype = C.c_void_p
         L.go_heap_free.argtypes = [C.c_void_p]
@@ -356,6 +359,48 @@ def exact_knn(X, Q, K, from_row=0, until_row=None):
     od = np.zeros((B, max(K, 1)), np.float32)
     oc = np.zeros(B, np.int32)
     rc = lib().go_exact_knn(X, n, d, from_row, until_row, Q, B, K, oi, od, oc)
+    if rc != 0:
+        raise ValueError("requirement failed")
+    return oi, od, oc
+
+
+def group_rows(assignments, coarse_centroids):
+    """WordVectors.grouped (WordVectors.scala:24-58) on row ids: rows stably ordered by their coarse
+    assignment (the reference additionally orders by word inside a group -- callers pass rows that
+    are already in word order), the centroids of the NON-EMPTY clusters in cluster order and the
+    first row of groups 1..g-1.  Returns (perm, group_centroids [g][d], offsets [g-1])."""
+    a = np.asarray(assignments, np.int32)
+    perm = np.argsort(a, kind="stable").astype(np.int32)
+    sa = a[perm]
+    starts = np.flatnonzero(np.r_[True, sa[1:] != sa[:-1]]) if len(sa) else np.zeros(0, np.int64)
+    cents = _f32(coarse_centroids)[sa[starts]] if len(sa) else _f32(coarse_centroids)[:0]
+    return perm, np.ascontiguousarray(cents), starts[1:].astype(np.int32)
+
+
+def group_residuals(X, perm, group_centroids, offsets):
+    """WordVectors.Grouped.residuals (WordVectors.scala:118-138): grouped row - its group's centroid."""
+    X = _f32(X)[perm]
+    n = X.shape[0]
+    bounds = np.r_[0, np.asarray(offsets, np.int64), n]
+    out = np.empty_like(X)
+    for c in range(len(bounds) - 1):
+        out[bounds[c]:bounds[c + 1]] = X[bounds[c]:bounds[c + 1]] - _f32(group_centroids)[c]
+    return out
+
+
+def grouped_query(idx, d, k, pq_cents, group_centroids, offsets, Q, K, strategy, limit):
+    """GroupedIndex.batchQuery (Index.scala:254-282); strategy 0 = LimitGroups, 1 = LimitVectors."""
+    Q = _f32(Q)
+    B = Q.shape[0]
+    arr = _i32(idx)
+    m, n = arr.shape
+    gc = _f32(group_centroids)
+    g = gc.shape[0]
+    off = _i32(offsets) if len(offsets) else np.zeros(1, np.int32)
+    oi = np.zeros((B, max(K, 1)), np.int32)
+    od = np.zeros((B, max(K, 1)), np.float32)
+    oc = np.zeros(B, np.int32)
+    rc = lib().go_grouped_query(arr, n, d, m, k, _f32(pq_cents), gc, off, g, Q, B, K, strategy, limit, oi, od, oc)
     if rc != 0:
         raise ValueError("requirement failed")
     return oi, od, oc

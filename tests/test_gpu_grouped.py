@@ -1,0 +1,113 @@
+"""GPU parity tests for GroupedIndex (Index.scala:231-308): coarse groups + PQ on residuals.
+Everything through the C ABI; the CPU oracle restates GroupedIndex.query literally (per-group
+TopKHeap, TopKHeap.merge in array order), and the GPU kernels run the same literal heaps, so ids,
+order and distances must be equal bit for bit -- also on data with exact distance ties."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gulon_amd
+    assert gulon_amd.native.device_count() >= 1
+    return gulon_amd
+
+
+def _build(oracle, g, n, d, groups, m, k, seed, dup=0, iters=3):
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((n, d)) + 3.0 * rng.integers(0, 4, (n, 1))).astype(np.float32)
+    if dup:
+        X[-dup:] = X[:dup]                                   # exact duplicates: distance ties everywhere
+    dm = g.DeviceMatrix.from_host(X)
+    coarse = g.KMeans.compute_clusters(g.Vectors(dm), g.KMeansConfig(groups, iters))
+    gv = g.group(dm, coarse)
+    pq = g.ProductQuantizer.apply(gv.residuals, g.ProductQuantizerConfig(k, m, iters))
+    return X, dm, coarse, gv, pq
+
+
+def _oracle_side(oracle, X, coarse, gv, pq, n):
+    """The same pipeline on the CPU: grouping, residuals, codes -- checked against the GPU's."""
+    assign = oracle.kmeans_assign(X, 0, X.shape[1], coarse.centroids, rng_batch=25000)
+    perm, cents, offsets = oracle.group_rows(assign, coarse.centroids)
+    assert np.array_equal(perm, gv.perm) and np.array_equal(offsets, gv.offsets)
+    assert np.array_equal(bits(cents), bits(gv.centroids))
+    R = oracle.group_residuals(X, perm, cents, offsets)
+    assert np.array_equal(bits(R), bits(gv.residuals.get_rows(np.arange(n, dtype=np.int32))))
+    return R, cents, offsets
+
+
+@pytest.mark.parametrize("strategy,limit", [("groups", 1), ("groups", 3), ("groups", 8), ("vectors", 500),
+                                            ("vectors", 1), ("vectors", 10 ** 9), ("groups", 100)])
+@pytest.mark.parametrize("n,d,groups,m,k,B,K,dup", [
+    (6000, 16, 12, 4, 16, 9, 5, 0),
+    (20000, 32, 40, 8, 256, 17, 10, 0),
+    (8000, 24, 10, 6, 64, 5, 10, 1500),          # duplicated rows: ties inside and across groups
+])
+def test_grouped_query_equals_reference(oracle, g, n, d, groups, m, k, B, K, dup, strategy, limit):
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + d, dup=dup)
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    strat = g.LimitGroups(limit) if strategy == "groups" else g.LimitVectors(limit)
+    index = g.Index.grouped(gv, pq, strat)
+    codes = index.data.indices()
+    assert np.array_equal(codes, oracle.pq_encode(R, m, k, pq.flat_centroids()))
+    rng = np.random.default_rng(1)
+    Q = np.concatenate([X[rng.integers(0, n, B - 2)], (rng.standard_normal((2, d)) * 2).astype(np.float32)])
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(codes, d, k, pq.flat_centroids(), cents, offsets, Q, K,
+                                      0 if strategy == "groups" else 1, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
+    index.close()
+
+
+def test_single_group_and_few_rows(oracle, g):
+    """One coarse cluster (offsets empty) and groups smaller than K."""
+    n, d, m, k, K = 300, 8, 2, 8, 20
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, 1, m, k, seed=5)
+    assert len(gv.offsets) == 0 and len(gv.centroids) == 1
+    index = g.Index.grouped(gv, pq, g.LimitGroups(4))
+    Q = X[:7]
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), gv.centroids, gv.offsets, Q, K,
+                                      0, 4)
+    assert np.array_equal(oc, ec) and np.array_equal(oi, ei) and np.array_equal(bits(od), bits(ed))
+    index.close()
+    X, dm, coarse, gv, pq = _build(oracle, g, 40, d, 12, m, k, seed=6)      # ~3 rows per group
+    index = g.Index.grouped(gv, pq, g.LimitGroups(3))
+    oi, od, oc = index.batch_query_raw(K, X[:5])
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), gv.centroids, gv.offsets,
+                                      X[:5], K, 0, 3)
+    assert np.array_equal(oc, ec)
+    for q in range(5):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+    index.close()
+
+
+def test_cosine_metric_normalises_the_query(oracle, g):
+    n, d, m, k, K = 5000, 16, 4, 32, 10
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, 8, m, k, seed=9)
+    index = g.Index.grouped(gv, pq, g.LimitGroups(3), metric="cosine")
+    Q = X[:6] * 7.5
+    oi, od, oc = index.batch_query_raw(K, Q)
+    Qn = np.stack([oracle.normalize(r) for r in Q])
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), gv.centroids, gv.offsets, Qn,
+                                      K, 0, 3)
+    assert np.array_equal(oi, ei) and np.array_equal(bits(od), bits(ed))
+    index.close()
+
+
+def test_bad_arguments(g):
+    import ctypes as C
+    from gulon_amd import native as N
+    h = C.c_void_p()
+    codes = np.zeros(4 * 10, np.uint8)
+    cents = np.zeros(256 * 8, np.float32)
+    gc = np.zeros(2 * 8, np.float32)
+    off = np.array([20], np.int32)                       # beyond n = 10
+    assert N.lib().gulon_grouped_index_create(codes, 10, 8, 4, 256, cents, gc, off, 2, C.byref(h)) == -1
