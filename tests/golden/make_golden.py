@@ -64,6 +64,22 @@ def main():
                         par_zero=o.kmeans_assign(Xt, 0, 2, Cz, 25000).astype(np.uint8),
                         serial_dup=o.kmeans_assign(Xt, 0, 2, Cd, 0).astype(np.uint8),
                         par_dup=o.kmeans_assign(Xt, 0, 2, Cd, 25000).astype(np.uint8))
+    # 5. GroupedIndex end to end on the pq_small data: 12 coarse clusters, residual PQ m = 4, k = 16
+    gcfg = dict(groups=12, m=4, k=16, iters=5)
+    Cc, _ = o.kmeans_compute_clusters(X, 0, d, gcfg["groups"], gcfg["iters"])
+    ga = o.kmeans_assign(X, 0, d, Cc, 25000)
+    perm, gcent, goff = o.group_rows(ga, Cc)
+    R = o.group_residuals(X, perm, gcent, goff)
+    rc, _, _ = o.pq_train(R, gcfg["m"], gcfg["k"], gcfg["iters"])
+    ridx = o.pq_encode(R, gcfg["m"], gcfg["k"], rc)
+    Qg = X[[7, 400, 1500, 1999, 3]]
+    out = {}
+    for name, (strat, lim) in {"groups3": (0, 3), "vectors600": (1, 600)}.items():
+        gi, gd, gc = o.grouped_query(ridx, d, gcfg["k"], rc, gcent, goff, Qg, 10, strat, lim)
+        out[f"{name}_idx"], out[f"{name}_dist"], out[f"{name}_count"] = gi, gd, gc
+    np.savez_compressed(os.path.join(HERE, "grouped_small.npz"), coarse_centroids=Cc, assignments=ga.astype(np.uint8),
+                        perm=perm, group_centroids=gcent, offsets=goff, residual_codebooks=rc,
+                        residual_codes=ridx.astype(np.uint8), queries=Qg, **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
