@@ -24,11 +24,11 @@ using gulon::DevBuf;
 struct gulon_grouped_index {
   gulon_index *pq = nullptr;       // residual codes + residual codebooks (row-blocked layout of scan.hip)
   int32_t n = 0, d = 0, g = 0;
-  DevBuf<float> gcent;             // [g][d] centroids of the non-empty groups
+  DevBuf<float> gcent, gcent_t;    // [g][d] centroids of the non-empty groups, and the [d][g] transpose
   DevBuf<int> bounds;              // [g+1] first row of every group, then n
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
-  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc;
+  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount;
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
 };
@@ -89,18 +89,18 @@ struct RegHeap {
 
 // ---- coarse search: distances of every query to every group centroid -------------------------
 // MathUtils.distanceSq(centroid, query): sum of (q_e - c_e)^2, e ascending, unfused.
-__global__ __launch_bounds__(256) void gq_cdist(const float *__restrict__ gcent, int g, int d,
+// gcent_t is the [d][g] transpose: consecutive threads (centroids) read consecutive addresses.
+__global__ __launch_bounds__(256) void gq_cdist(const float *__restrict__ gcent_t, int g, int d,
                                                 const float *__restrict__ Q, int B, float *__restrict__ out) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)B * g) return;
-  const int q = (int)(t / g), c = (int)(t - (long long)q * g);
-  const float *x = gcent + (size_t)c * d, *y = Q + (size_t)q * d;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (c >= g) return;
+  const float *y = Q + (size_t)q * d;
   float sum = 0.f;
   for (int e = 0; e < d; e++) {
-    const float dx = y[e] - x[e];
+    const float dx = y[e] - gcent_t[(size_t)e * g + c];
     sum += dx * dx;
   }
-  out[t] = sum;
+  out[(size_t)q * g + c] = sum;
 }
 
 // LimitGroups(limit <= 63): literal exactNearestNeighbours(centroids, query, limit).deleteAll()
@@ -176,72 +176,163 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
 }
 
 // ---- one searched group of one query -------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(64) void gq_group_scan(const uint8_t *__restrict__ codes, int ng, int m, int m_pad, int k,
+// LITERAL = true: the group's literal TopKHeap, stored in array order (hk/hv/hs).  With a query list
+// (qlist/qcount on the device) only the listed queries are processed -- the tie-flagged ones.
+// LITERAL = false: the K+1 smallest (distance, row) pairs of the group as an ascending list
+// (hv/hk hold K+1 entries per pair, padded with (+inf, INT_MAX)); hs = 1 if a NaN distance was seen.
+constexpr int GQ_WAVES = 4;    // (query, group) pairs per workgroup: they share the staged codebook slices
+constexpr int GQ_RPT = 8;      // centroid components prefetched per thread (sub-vectors up to 8 wide are fully overlapped)
+constexpr int GQ_PD = 4;       // quantizers whose codebooks are in flight
+template <int VEC, bool LITERAL>
+__global__ __launch_bounds__(64 * GQ_WAVES) void gq_group_scan(const uint8_t *__restrict__ codes, int ng, int m, int m_pad, int k,
                                                     int d, const float *__restrict__ pq_cents,
                                                     const int *__restrict__ from, const int *__restrict__ sdim,
                                                     const float *__restrict__ gcent, const int *__restrict__ bounds,
                                                     const float *__restrict__ Q, const int *__restrict__ nn,
                                                     int nn_stride, const int *__restrict__ nn_cnt, int stride, int K,
                                                     int *__restrict__ hk, float *__restrict__ hv,
-                                                    int *__restrict__ hs) {
+                                                    int *__restrict__ hs, const int *__restrict__ qlist,
+                                                    const int *__restrict__ qcount, int slice_floats) {
   using Word = typename CodeWord<VEC>::type;
-  extern __shared__ float gtab[];   // m_pad * 256 table entries, then the d residual components
-  const int q = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
-  if (t >= nn_cnt[q]) return;
-  const int c = nn[(size_t)q * nn_stride + t];
+  // per wave: m_pad * 256 table entries + d residual components; then one codebook slice (k * smax floats)
+  extern __shared__ float gq_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x * GQ_WAVES + wave;           // searched-group slot of this wave
+  float *gtab = gq_lds + (size_t)wave * (m_pad * 256 + d);
   float *res = gtab + m_pad * 256;
-  for (int e = lane; e < d; e += 64) res[e] = Q[(size_t)q * d + e] - gcent[(size_t)c * d + e];   // MathUtils.subtract
+  float *slice = gq_lds + (size_t)GQ_WAVES * (m_pad * 256 + d);
+  const int nq = qlist ? *qcount : (int)gridDim.y;
+  for (int fy = blockIdx.y; fy < nq; fy += gridDim.y) {
+  const int q = qlist ? qlist[fy] : fy;
+  const bool live = t < nn_cnt[q];                       // wave-uniform; dead waves still help staging
+  const int c = live ? nn[(size_t)q * nn_stride + t] : 0;
   __syncthreads();
-  // Index.prepareQuery on the residual: T[j][c'] = sum_e (r[from_j+e] - cent_j[c'][e])^2, e ascending, unfused
-  for (int e = lane; e < m_pad * 256; e += 64) {
-    const int j = e >> 8, cc = e & 255;
-    float acc = 0.f;
-    if (j < m && cc < k) {
-      const int fr = from[j], s = sdim[j];
-      const float *cent = pq_cents + (size_t)k * fr + (size_t)cc * s;
-      for (int x = 0; x < s; x++) {
-        const float dd = res[fr + x] - cent[x];
-        acc += dd * dd;
+  if (live)
+    for (int e = lane; e < d; e += 64) res[e] = Q[(size_t)q * d + e] - gcent[(size_t)c * d + e];   // MathUtils.subtract
+  // Index.prepareQuery on the residual: T[j][c'] = sum_e (r[from_j+e] - cent_j[c'][e])^2, e ascending, unfused.
+  // The codebook of quantizer j (k * s_j contiguous floats) is staged once for the four pairs.
+  // The codebooks of the next GQ_PD quantizers are in flight in registers (GQ_RPT floats per thread
+  // each) while this one is used: at two workgroups per CU a single global round trip costs more
+  // than a quantizer's 256 x s table entries (LDS holds one slice at a time).
+  static_assert(64 * GQ_WAVES == 256, "thread = centroid staging assumes 256 threads");
+  float pre[GQ_PD][GQ_RPT];
+  // thread = centroid (k <= 256 = GQ_THREADS): component x of its centroid, no index arithmetic
+  auto fetch = [&](int j, float (&dst)[GQ_RPT]) {
+    const int fr = j < m ? from[j] : 0, sj = j < m ? sdim[j] : 0;
+    const float *cent = pq_cents + (size_t)k * fr + (size_t)tid * sj;
+#pragma unroll
+    for (int u = 0; u < GQ_RPT; u++) dst[u] = (tid < k && u < sj) ? cent[u] : 0.f;
+  };
+#pragma unroll
+  for (int p = 0; p < GQ_PD; p++) fetch(p, pre[p]);
+  for (int j0 = 0; j0 < m_pad; j0 += GQ_PD) {            // m_pad is a multiple of 4
+#pragma unroll
+    for (int p = 0; p < GQ_PD; p++) {
+      const int j = j0 + p;
+      const int fr = j < m ? from[j] : 0, sj = j < m ? sdim[j] : 0;
+      float *sl = slice;
+      __syncthreads();                                   // slice j-1 is no longer read
+      // stored transposed, [x][centroid]: the lanes of a wave then read consecutive addresses
+#pragma unroll
+      for (int u = 0; u < GQ_RPT; u++)
+        if (u < sj) sl[u * 256 + tid] = pre[p][u];
+      for (int x = GQ_RPT; x < sj; x++)                  // long sub-vectors: the rest straight from memory
+        sl[x * 256 + tid] = tid < k ? pq_cents[(size_t)k * fr + (size_t)tid * sj + x] : 0.f;
+      if (j + GQ_PD < m_pad) fetch(j + GQ_PD, pre[p]);
+      __syncthreads();                                   // slice j complete
+      if (live) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};             // centroids lane, lane + 64, lane + 128, lane + 192
+        for (int x = 0; x < sj; x++) {
+          const float rx = res[fr + x];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float dd = rx - sl[x * 256 + lane + 64 * i];
+            acc[i] += dd * dd;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) gtab[j * 256 + lane + 64 * i] = lane + 64 * i < k ? acc[i] : 0.f;
       }
     }
-    gtab[e] = acc;
   }
   __syncthreads();
+  if (!live) continue;
   const int row_from = bounds[c], row_until = bounds[c + 1];
+  const int keff = K + 1;
   RegHeap h(K, lane);
+  WaveList wl;
+  wl.init();
+  int cnt = 0, saw_nan = 0;
   const Word *cw = reinterpret_cast<const Word *>(codes);
-  for (int rb = row_from / 64; rb * 64 < row_until; rb++) {
+  // the first code words of the next GQ_PD row blocks stay in flight
+  const int rb_first = row_from / 64, rb_end = (row_until + 63) / 64;
+  Word wq[GQ_PD];
+#pragma unroll
+  for (int p = 0; p < GQ_PD; p++) wq[p] = rb_first + p < rb_end ? cw[((size_t)(rb_first + p) * ng) * 64 + lane] : Word{};
+  for (int rb0 = rb_first; rb0 < rb_end; rb0 += GQ_PD) {
+#pragma unroll
+  for (int p = 0; p < GQ_PD; p++) {
+    const int rb = rb0 + p;
+    if (rb >= rb_end) break;
     float acc = 0.f;                 // PQIndex.distances: j ascending, unfused fp32
+    const Word w0 = wq[p];
+    if (rb + GQ_PD < rb_end) wq[p] = cw[((size_t)(rb + GQ_PD) * ng) * 64 + lane];
     for (int gi = 0; gi < ng; gi++) {
-      const Word w = cw[((size_t)rb * ng + gi) * 64 + lane];
+      const Word w = gi == 0 ? w0 : cw[((size_t)rb * ng + gi) * 64 + lane];
       const float *tj = gtab + gi * VEC * 256;
 #pragma unroll
       for (int b = 0; b < VEC; b++) acc += tj[b * 256 + code_byte<VEC>(w, b)];
     }
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
-    // rows in ascending order through heap.update; the ballot only skips rows the heap would
-    // reject anyway (full and root <= value -- NaN compares false and is rejected like there)
-    unsigned long long mk = __ballot(valid && (h.size < K || h.val(0) > acc));
-    while (mk) {
-      const int l = __ffsll((long long)mk) - 1;
-      mk &= mk - 1;
-      const float x = readlane_f(acc, l);
-      if (h.would_insert(x)) h.update(rb * 64 + l, x);
+    if (LITERAL) {
+      // rows in ascending order through heap.update; the ballot only skips rows the heap would
+      // reject anyway (full and root <= value -- NaN compares false and is rejected like there)
+      unsigned long long mk = __ballot(valid && (h.size < K || h.val(0) > acc));
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float x = readlane_f(acc, l);
+        if (h.would_insert(x)) h.update(rb * 64 + l, x);
+      }
+    } else {
+      if (__ballot(valid && acc != acc) != 0ull) saw_nan = 1;   // the heap keeps NaNs while it is not full
+      unsigned long long mk = __ballot(valid && (cnt < keff || wl.accepts(acc, row)));
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float x = readlane_f(acc, l);
+        const int r = rb * 64 + l;
+        if (cnt < keff || wl.accepts(x, r)) {
+          wl.insert(x, r, keff, lane);
+          if (cnt < keff) cnt++;
+        }
+      }
     }
   }
-  const size_t o = ((size_t)q * stride + t) * K;
-  if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
-  if (lane == 0) hs[(size_t)q * stride + t] = h.size;
+  }
+  if (LITERAL) {
+    const size_t o = ((size_t)q * stride + t) * K;
+    if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
+    if (lane == 0) hs[(size_t)q * stride + t] = h.size;
+  } else {
+    const size_t o = ((size_t)q * stride + t) * keff;
+    if (lane < keff) { hk[o + lane] = wl.i; hv[o + lane] = wl.v; }
+    if (lane == 0) hs[(size_t)q * stride + t] = saw_nan;
+  }
+  }
 }
 
 // ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
 __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
                                                const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
                                                int K, int *__restrict__ out_idx, float *__restrict__ out_dist,
-                                               int *__restrict__ out_count) {
-  const int q = blockIdx.x, lane = threadIdx.x;
+                                               int *__restrict__ out_count, const int *__restrict__ qlist,
+                                               const int *__restrict__ qcount) {
+  const int lane = threadIdx.x;
+  const int nq = qlist ? *qcount : (int)gridDim.x;
+  for (int fx = blockIdx.x; fx < nq; fx += gridDim.x) {
+  const int q = qlist ? qlist[fx] : fx;
   RegHeap h(K, lane);
   const int cnt = nn_cnt[q];
   for (int t = 0; t < cnt; t++) {
@@ -259,6 +350,56 @@ __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const
   }
   if (lane >= live && lane < K) { out_idx[(size_t)q * K + lane] = -1; out_dist[(size_t)q * K + lane] = INFINITY; }
   if (lane == 0 && out_count) out_count[q] = live;
+  }
+}
+
+// Tie-free fast path: merge the groups' ascending (K+1)-lists under the (distance, row) order.
+// Wherever the K+1 smallest distances of the searched rows are pairwise different this IS the
+// reference's answer; a query with equal neighbours among them (or a NaN distance anywhere) is
+// appended to qlist and redone by the literal kernels.
+__global__ __launch_bounds__(64) void gq_merge_fast(const int *__restrict__ li, const float *__restrict__ lv,
+                                                    const int *__restrict__ nanflag,
+                                                    const int *__restrict__ nn_cnt, int stride, int K,
+                                                    int *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                    int *__restrict__ out_count, int *__restrict__ qlist,
+                                                    int *__restrict__ qcount) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int keff = K + 1;
+  WaveList wl;
+  wl.init();
+  const int cnt = nn_cnt[q];
+  const int total = cnt * keff;
+  int nanany = 0;
+  for (int t = lane; t < cnt; t += 64) nanany |= nanflag[(size_t)q * stride + t];
+  nanany = __ballot(nanany != 0) != 0ull;
+  const size_t o = (size_t)q * stride * keff;
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    const float cv = e < total ? lv[o + e] : INFINITY;
+    const int cr = e < total ? li[o + e] : INT_MAX;
+    unsigned long long mk = __ballot(cr != INT_MAX && wl.accepts(cv, cr));
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float v = readlane_f(cv, l);
+      const int r = readlane_i(cr, l);
+      if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
+    }
+  }
+  const int live = __popcll(__ballot(lane < K && wl.i != INT_MAX));
+  if (lane < K) {
+    const bool ok = wl.i != INT_MAX;
+    out_idx[(size_t)q * K + lane] = ok ? wl.i : -1;
+    out_dist[(size_t)q * K + lane] = ok ? wl.v : INFINITY;
+  }
+  const float nv = __shfl_down(wl.v, 1);
+  const int ni = __shfl_down(wl.i, 1);
+  const bool tie = wl.i != INT_MAX && ni != INT_MAX && wl.v == nv && lane + 1 < keff;
+  const bool flagged = __ballot(tie) != 0ull || nanany;
+  if (lane == 0) {
+    if (out_count) out_count[q] = live;
+    if (flagged) qlist[atomicAdd(qcount, 1)] = q;
+  }
 }
 
 // residual dataset in grouped order: out[i] = X[perm[i]] - gcent[group_of[i]]
@@ -293,7 +434,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   gx->cdist.ensure((size_t)B * g);
   gx->nn.ensure((size_t)B * nn_stride);
   gx->nn_cnt.ensure((size_t)B);
-  hipLaunchKernelGGL(gq_cdist, dim3(ceil_div((long long)B * g, 256)), dim3(256), 0, st, gx->gcent.p, g, gx->d, dQ, B,
+  hipLaunchKernelGGL(gq_cdist, dim3(ceil_div(g, 256), B), dim3(256), 0, st, gx->gcent_t.p, g, gx->d, dQ, B,
                      gx->cdist.p);
   if (strategy == 0 && limit <= GULON_MAX_K && limit >= 1) {
     hipLaunchKernelGGL(gq_nearest_groups, dim3(B), dim3(64), 0, st, gx->cdist.p, g, limit, gx->nn.p, nn_stride,
@@ -319,23 +460,63 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     }
   }
   HIP_CHECK(hipGetLastError());
-  gx->hk.ensure((size_t)B * stride * K);
-  gx->hv.ensure((size_t)B * stride * K);
+  const int keff = K + 1;
+  const bool literal_only = getenv("GULON_GROUPED_LITERAL") != nullptr;   // testing aid: literal kernels for every query
+  gx->hk.ensure((size_t)B * stride * keff);
+  gx->hv.ensure((size_t)B * stride * keff);
   gx->hs.ensure((size_t)B * stride);
-  const size_t lds = ((size_t)ix->m_pad * 256 + ix->d) * sizeof(float);
-#define GS(V)                                                                                                      \
-  {                                                                                                                \
-    auto kern = gq_group_scan<V>;                                                                                  \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds));                                                                      \
-    hipLaunchKernelGGL(kern, dim3(stride, B), dim3(64), lds, st, ix->codes.p, ix->ng, ix->m, ix->m_pad, ix->k, ix->d, \
-                       ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride,    \
-                       gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p);                                             \
+  gx->qlist.ensure((size_t)B);
+  gx->qcount.ensure(1);
+  int smax = 1;
+  {
+    std::vector<int> fr, un;
+    subvectors(ix->d, ix->m, fr, un);
+    for (int j = 0; j < ix->m; j++) smax = std::max(smax, un[j] - fr[j]);
   }
-  if (ix->vec == 16) GS(16) else GS(4)
+  const int slice_floats = 256 * smax;               // [x][256], transposed
+  const size_t lds = ((size_t)GQ_WAVES * (ix->m_pad * 256 + ix->d) + (size_t)slice_floats) * sizeof(float);
+  GULON_UNSUPPORTED(lds > 160 * 1024, "grouped query needs %zu B of LDS (m = %d, d = %d)", lds, ix->m, ix->d);
+  auto scan = [&](bool literal, int gy, const int *qlist, const int *qcount) {
+#define GS(V, L)                                                                                                    \
+    {                                                                                                               \
+      auto kern = gq_group_scan<V, L>;                                                                              \
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+      hipLaunchKernelGGL(kern, dim3(ceil_div(stride, GQ_WAVES), gy), dim3(64 * GQ_WAVES), lds, st, ix->codes.p, ix->ng, \
+                         ix->m, ix->m_pad, ix->k,                                                                  \
+                         ix->d, ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p,       \
+                         nn_stride, gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p, qlist, qcount,          \
+                         slice_floats);                                                                            \
+    }
+    if (ix->vec == 16) { if (literal) GS(16, true) else GS(16, false) }
+    else               { if (literal) GS(4, true) else GS(4, false) }
 #undef GS
-  hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
-                     d_od, d_oc);
+    HIP_CHECK(hipGetLastError());
+  };
+  if (literal_only) {
+    scan(true, B, nullptr, nullptr);
+    hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+                       d_od, d_oc, (const int *)nullptr, (const int *)nullptr);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  // fast path for every query, then the literal heaps for the tie-flagged ones (usually none)
+  HIP_CHECK(hipMemsetAsync(gx->qcount.p, 0, sizeof(int), st));
+  scan(false, B, nullptr, nullptr);
+  hipLaunchKernelGGL(gq_merge_fast, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K,
+                     d_oi, d_od, d_oc, gx->qlist.p, gx->qcount.p);
+  HIP_CHECK(hipGetLastError());
+  if (getenv("GULON_GROUPED_STATS")) {   // debugging aid
+    HIP_CHECK(hipStreamSynchronize(st));
+    int nfl = 0;
+    HIP_CHECK(hipMemcpy(&nfl, gx->qcount.p, sizeof(int), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[grouped] %d of %d queries redone with literal heaps; %d groups searched per query at most\n", nfl, B,
+            stride);
+  }
+  const int fy = std::min(B, 16);
+  scan(true, fy, gx->qlist.p, gx->qcount.p);
+  hipLaunchKernelGGL(gq_merge, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+                     d_od, d_oc, gx->qlist.p, gx->qcount.p);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -395,6 +576,13 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
     gx->pq = pq;
     gx->n = n; gx->d = d; gx->g = g;
     gx->gcent.upload(group_centroids, (size_t)g * d);
+    {
+      std::vector<float> tr((size_t)g * d);
+      for (int c = 0; c < g; c++)
+        for (int e = 0; e < d; e++) tr[(size_t)e * g + c] = group_centroids[(size_t)c * d + e];
+      gx->gcent_t.upload(tr.data(), tr.size());
+      HIP_CHECK(hipDeviceSynchronize());   // tr goes out of scope
+    }
     gx->bounds.upload(bounds.data(), bounds.size());
     HIP_CHECK(hipDeviceSynchronize());
     *out = gx.release();
