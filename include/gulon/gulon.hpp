@@ -9,6 +9,7 @@
 // Paths cited are relative to /root/reference/core/src/main/scala/net/tixxit/gulon/.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -34,6 +35,14 @@ class Matrix {
  public:
   Matrix(const float *data, int rows, int cols) : rows_(rows), cols_(cols) {
     check(gulon_dataset_create(data, rows, cols, &h_));
+  }
+  // WordVectors.Grouped.residuals (WordVectors.scala:118-138): out[i] = m[perm[i]] - centroids[groupOf[i]]
+  static Matrix groupResiduals(const Matrix &m, const std::vector<int32_t> &perm, const std::vector<int32_t> &groupOf,
+                               const std::vector<float> &centroids, int groups) {
+    Matrix r;
+    r.rows_ = m.rows_; r.cols_ = m.cols_;
+    check(gulon_dataset_group_residuals(m.h_, perm.data(), groupOf.data(), centroids.data(), groups, &r.h_));
+    return r;
   }
   static Matrix synthetic(int rows, int cols, int kind, uint64_t seed, int ncentres) {
     Matrix m;
@@ -208,7 +217,86 @@ class PQIndex {                       // Index.scala:385-441
   int dimension_, length_;
 };
 
+// WordVectors.Grouped without the keys (WordVectors.scala:24-58,118-138): rows regrouped by coarse
+// cluster, the centroids of the non-empty clusters, the group offsets and the residual matrix.
+struct GroupedVectors {
+  std::vector<int32_t> perm;          // grouped position -> original row
+  std::vector<float> centroids;       // [g][d]
+  std::vector<int32_t> offsets;       // [g-1]
+  std::unique_ptr<Matrix> residuals;  // grouped row - its group's centroid, resident in HBM
+  int groups() const { return (int)offsets.size() + 1; }
+};
+
+// WordVectors.grouped: parAssign, stable ordering by cluster (rows keep their order inside a group).
+inline GroupedVectors group(const Matrix &vectors, const KMeans &clustering) {
+  if (clustering.k() <= 0) throw std::invalid_argument("requirement failed: must have at least 1 cluster");
+  const int n = vectors.rows(), d = vectors.cols();
+  const std::vector<int32_t> a = clustering.parAssign(Vectors{&vectors, 0, d});
+  GroupedVectors gv;
+  gv.perm.resize(n);
+  for (int i = 0; i < n; i++) gv.perm[i] = i;
+  std::stable_sort(gv.perm.begin(), gv.perm.end(), [&](int32_t x, int32_t y) { return a[x] < a[y]; });
+  std::vector<int32_t> groupOf(n);
+  int g = 0;
+  for (int i = 0; i < n; i++) {
+    const int c = a[gv.perm[i]];
+    if (i == 0 || c != a[gv.perm[i - 1]]) {
+      if (i > 0) gv.offsets.push_back(i);
+      gv.centroids.insert(gv.centroids.end(), clustering.centroids.begin() + (size_t)c * d,
+                          clustering.centroids.begin() + (size_t)(c + 1) * d);
+      g++;
+    }
+    groupOf[i] = g - 1;
+  }
+  if (n > 0) gv.residuals.reset(new Matrix(Matrix::groupResiduals(vectors, gv.perm, groupOf, gv.centroids, g)));
+  return gv;
+}
+
+class GroupedIndex {                  // Index.scala:231-308 over row ids (grouped positions)
+ public:
+  enum class Strategy { LimitGroups = 0, LimitVectors = 1 };
+  GroupedIndex(const ProductQuantizer &residualsQuantizer, const EncodedMatrix &encodedResiduals,
+               const std::vector<float> &centroids, const std::vector<int32_t> &offsets, Strategy strategy, int limit)
+      : dimension_(residualsQuantizer.dimension), strategy_(strategy), limit_(limit) {
+    const int g = (int)offsets.size() + 1;
+    if ((size_t)g * dimension_ != centroids.size()) throw std::logic_error("centroids.length != offsets.length + 1");
+    check(gulon_grouped_index_create(encodedResiduals.packed.data(), encodedResiduals.length, dimension_,
+                                     residualsQuantizer.numQuantizers, residualsQuantizer.numClusters,
+                                     residualsQuantizer.centroids.data(), centroids.data(),
+                                     offsets.empty() ? nullptr : offsets.data(), g, &h_));
+  }
+  GroupedIndex(const GroupedIndex &) = delete;
+  GroupedIndex &operator=(const GroupedIndex &) = delete;
+  ~GroupedIndex() { if (h_) gulon_grouped_index_destroy(h_); }
+  // GroupedIndex.batchQuery (:254-282): searchSpace, per-group PQIndex.query on the residual, heap.merge
+  std::vector<Result> batchQuery(int k, const std::vector<float> &queries) const {
+    const int b = dimension_ ? (int)(queries.size() / dimension_) : 0;
+    std::vector<int32_t> idx((size_t)b * k + 1), cnt(b + 1);
+    std::vector<float> dist((size_t)b * k + 1);
+    check(gulon_grouped_index_batch_query(h_, queries.data(), b, k, (int32_t)strategy_, limit_, idx.data(),
+                                          dist.data(), cnt.data()));
+    std::vector<Result> out(b);
+    for (int q = 0; q < b; q++) {
+      out[q].rows.assign(idx.begin() + (size_t)q * k, idx.begin() + (size_t)q * k + cnt[q]);
+      out[q].distances.assign(dist.begin() + (size_t)q * k, dist.begin() + (size_t)q * k + cnt[q]);
+    }
+    return out;
+  }
+
+ private:
+  gulon_grouped_index *h_ = nullptr;
+  int dimension_;
+  Strategy strategy_;
+  int limit_;
+};
+
 namespace Index {
+// Index.grouped (Index.scala:133-147): the quantizer is one on the residuals.
+inline std::unique_ptr<GroupedIndex> grouped(const GroupedVectors &gv, const ProductQuantizer &residualsQuantizer,
+                                             GroupedIndex::Strategy strategy, int limit) {
+  return std::unique_ptr<GroupedIndex>(new GroupedIndex(residualsQuantizer, residualsQuantizer.encode(*gv.residuals),
+                                                        gv.centroids, gv.offsets, strategy, limit));
+}
 // Index.sorted (Index.scala:107-114): encode, then wrap.
 inline std::unique_ptr<PQIndex> sorted(const Matrix &vectors, const ProductQuantizer &pq) {
   return std::unique_ptr<PQIndex>(new PQIndex(pq, pq.encode(vectors)));

@@ -120,3 +120,49 @@ JNIEXPORT void JNICALL Java_net_tixxit_gulon_hip_Native_kmeansAssign(JNIEnv *env
   throw_status(env, rc);
 }
 /* kmeansInit / kmeansUpdate / kmeansIterate / kmeansTrain / exactKnn / prepareQuery follow the same pattern. */
+
+/* GroupedIndex (Index.scala:231-308) */
+JNIEXPORT jlong JNICALL Java_net_tixxit_gulon_hip_Native_groupResiduals(JNIEnv *env, jclass c, jlong ds, jintArray perm,
+                                                                      jintArray groupOf, jfloatArray centroids, jint g) {
+  gulon_dataset *out = NULL;
+  jint *p = (*env)->GetIntArrayElements(env, perm, NULL), *go = (*env)->GetIntArrayElements(env, groupOf, NULL);
+  jfloat *ce = (*env)->GetFloatArrayElements(env, centroids, NULL);
+  int32_t rc = gulon_dataset_group_residuals((gulon_dataset *)(intptr_t)ds, (const int32_t *)p, (const int32_t *)go, ce, g, &out);
+  (*env)->ReleaseIntArrayElements(env, perm, p, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, groupOf, go, JNI_ABORT);
+  (*env)->ReleaseFloatArrayElements(env, centroids, ce, JNI_ABORT);
+  if (throw_status(env, rc)) return 0;
+  return (jlong)(intptr_t)out;
+}
+JNIEXPORT jlong JNICALL Java_net_tixxit_gulon_hip_Native_groupedIndexCreate(JNIEnv *env, jclass c, jbyteArray codes, jint n,
+                                                                          jint d, jint m, jint k, jfloatArray pqCents,
+                                                                          jfloatArray groupCents, jintArray offsets, jint g) {
+  gulon_grouped_index *out = NULL;
+  jbyte *co = (*env)->GetByteArrayElements(env, codes, NULL);
+  jfloat *pc = (*env)->GetFloatArrayElements(env, pqCents, NULL), *gc = (*env)->GetFloatArrayElements(env, groupCents, NULL);
+  jint *of = (*env)->GetIntArrayElements(env, offsets, NULL);
+  int32_t rc = gulon_grouped_index_create((const uint8_t *)co, n, d, m, k, pc, gc, (const int32_t *)of, g, &out);
+  (*env)->ReleaseByteArrayElements(env, codes, co, JNI_ABORT);
+  (*env)->ReleaseFloatArrayElements(env, pqCents, pc, JNI_ABORT);
+  (*env)->ReleaseFloatArrayElements(env, groupCents, gc, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, offsets, of, JNI_ABORT);
+  if (throw_status(env, rc)) return 0;
+  return (jlong)(intptr_t)out;
+}
+JNIEXPORT void JNICALL Java_net_tixxit_gulon_hip_Native_groupedIndexDestroy(JNIEnv *env, jclass c, jlong h) {
+  gulon_grouped_index_destroy((gulon_grouped_index *)(intptr_t)h);
+}
+JNIEXPORT void JNICALL Java_net_tixxit_gulon_hip_Native_groupedIndexBatchQuery(JNIEnv *env, jclass c, jlong h,
+                                                                             jfloatArray queries, jint b, jint k,
+                                                                             jint strategy, jint limit, jintArray outIdx,
+                                                                             jfloatArray outDist, jintArray outCount) {
+  jfloat *q = (*env)->GetFloatArrayElements(env, queries, NULL), *od = (*env)->GetFloatArrayElements(env, outDist, NULL);
+  jint *oi = (*env)->GetIntArrayElements(env, outIdx, NULL), *oc = (*env)->GetIntArrayElements(env, outCount, NULL);
+  int32_t rc = gulon_grouped_index_batch_query((gulon_grouped_index *)(intptr_t)h, q, b, k, strategy, limit, (int32_t *)oi,
+                                               od, (int32_t *)oc);
+  (*env)->ReleaseFloatArrayElements(env, queries, q, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, outIdx, oi, 0);
+  (*env)->ReleaseFloatArrayElements(env, outDist, od, 0);
+  (*env)->ReleaseIntArrayElements(env, outCount, oc, 0);
+  throw_status(env, rc);
+}

@@ -23,6 +23,15 @@ object Native {
                               outFlags: Array[Int]): Unit
   @native def kmeansAssign(ds: Long, from: Int, s: Int, centroids: Array[Float], k: Int, rngBatch: Int,
                            assignments: Array[Int]): Unit
+  // GroupedIndex (Index.scala:231-308); strategy 0 = LimitGroups, 1 = LimitVectors
+  @native def groupResiduals(ds: Long, perm: Array[Int], groupOf: Array[Int], centroids: Array[Float],
+                             groups: Int): Long
+  @native def groupedIndexCreate(codes: Array[Byte], n: Int, d: Int, m: Int, k: Int, pqCents: Array[Float],
+                                 groupCents: Array[Float], offsets: Array[Int], groups: Int): Long
+  @native def groupedIndexDestroy(handle: Long): Unit
+  @native def groupedIndexBatchQuery(handle: Long, queries: Array[Float], b: Int, k: Int, strategy: Int,
+                                     limit: Int, outIdx: Array[Int], outDist: Array[Float],
+                                     outCount: Array[Int]): Unit
 
   /** Matrix.data (jagged) -> one direct row-major buffer (Matrix.scala:3). */
   def flatten(rows: Array[Array[Float]], cols: Int): FloatBuffer = {

@@ -17,6 +17,9 @@ int32_t go_pq_batch_query(const int32_t *idx, int32_t n, int32_t d, int32_t m, i
                           int32_t *out_idx, float *out_dist, int32_t *out_count);
 void go_kmeans_assign(const float *X, int32_t n, int32_t ld, int32_t from, int32_t s, const float *C, int32_t k,
                       int32_t rng_batch, int32_t *assignments);
+int32_t go_grouped_query(const int32_t *idx, int32_t n, int32_t d, int32_t m, int32_t k, const float *pq_cents,
+                         const float *gcent, const int32_t *offsets, int32_t g, const float *Q, int32_t B, int32_t K,
+                         int32_t strategy, int32_t limit, int32_t *out_idx, float *out_dist, int32_t *out_count);
 }
 
 static int fails = 0;
@@ -75,6 +78,32 @@ int main() {
   threw = false;
   try { index->batchQuery(K, Q, 0, n + 1); } catch (const std::invalid_argument &) { threw = true; }
   EXPECT(threw);
+
+  // GroupedIndex: coarse KMeans -> group -> residual PQ -> Index.grouped -> batchQuery (Index.scala:231-308)
+  {
+    gulon::KMeans::Config cc;
+    cc.numClusters = 9; cc.maxIterations = iters;
+    gulon::KMeans coarse = gulon::KMeans::computeClusters(gulon::Vectors{&data, 0, d}, cc);
+    gulon::GroupedVectors gv = gulon::group(data, coarse);
+    EXPECT((int)gv.perm.size() == n && gv.groups() >= 1);
+    gulon::ProductQuantizer rpq = gulon::ProductQuantizer::apply(*gv.residuals, {k, m, iters});
+    auto gindex = gulon::Index::grouped(gv, rpq, gulon::GroupedIndex::Strategy::LimitGroups, 3);
+    auto gres = gindex->batchQuery(K, Q);
+    gulon::EncodedMatrix rem = rpq.encode(*gv.residuals);
+    std::vector<int32_t> ridx((size_t)m * n);
+    for (size_t i = 0; i < ridx.size(); i++) ridx[i] = rem.packed[i];
+    std::vector<int32_t> gi((size_t)B * K), gc(B);
+    std::vector<float> gd((size_t)B * K);
+    std::vector<int32_t> off = gv.offsets;
+    if (off.empty()) off.push_back(0);
+    EXPECT(go_grouped_query(ridx.data(), n, d, m, k, rpq.centroids.data(), gv.centroids.data(), off.data(),
+                            gv.groups(), Q.data(), B, K, 0, 3, gi.data(), gd.data(), gc.data()) == 0);
+    for (int q = 0; q < B; q++) {
+      EXPECT((int)gres[q].rows.size() == gc[q]);
+      EXPECT(memcmp(gres[q].distances.data(), gd.data() + (size_t)q * K, sizeof(float) * gc[q]) == 0);
+      EXPECT(memcmp(gres[q].rows.data(), gi.data() + (size_t)q * K, sizeof(int32_t) * gc[q]) == 0);
+    }
+  }
 
   if (fails == 0) printf("cpp host api OK\n");
   return fails ? 1 : 0;
