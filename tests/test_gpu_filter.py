@@ -180,3 +180,31 @@ def test_sharded_partial_lists_through_the_filter(oracle, g, tune):
     from gulon_amd.topk import merge_partials
     out_i, out_d, out_c, out_f = merge_partials(np.stack(pd), np.stack(pi), K)
     assert np.array_equal(out_i, oi) and np.array_equal(bits(out_d), bits(od))
+
+
+def test_randomised_shapes_against_the_oracle(oracle, g, tune):
+    """Differential test over seeded random shapes: ragged m, small k, sub-ranges, duplicate rows,
+    queries on and off the data -- filtered scan == oracle, bit for bit."""
+    rng = np.random.default_rng(20260904)
+    for case in range(24):
+        d = int(rng.integers(4, 97))
+        m = int(rng.integers(1, min(d, 40) + 1))
+        k = int(rng.choice([2, 3, 16, 17, 100, 256]))
+        n = int(rng.integers(600, 40000))
+        B = int(rng.integers(1, 40))
+        K = int(rng.choice([1, 2, 10, 31, 63]))
+        dup = int(rng.integers(0, n // 4)) if case % 3 == 0 else 0
+        frm = int(rng.integers(0, n // 3)) if case % 4 == 1 else 0
+        until = int(rng.integers(frm + (n - frm) // 2, n + 1)) if case % 4 == 1 else n
+        tune(GULON_FILTER_NADD=int(rng.choice([0, 2, 4])), GULON_FILTER_PERIOD=int(rng.choice([4, 8, 32])),
+             GULON_FILTER_STAGE1=int(rng.choice([1, 2, 3])))
+        cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=1000 + case, dup=dup)
+        Q = rng.standard_normal((B, d)).astype(np.float32)
+        ix = g.PQIndex(pq, enc)
+        res = ix.batch_query(K, Q, frm, until)
+        oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, until)
+        try:
+            _check(oracle, res, oi, od, oc)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n={n} d={d} m={m} k={k} B={B} K={K} dup={dup} range=[{frm},{until})") from e
+        ix.close()
