@@ -3,6 +3,7 @@
 //   mode 2: lane pairs read the two halves of one random 32-B entry
 //   mode 4: lane quads read the four quarters of one random 64-B entry
 //   mode 16: 16 lanes read one random 256-B row (conflict-free reference)
+//   mode 0: random row per lane, column = lane % 16 (distinct bank groups inside each 16-lane group)
 // build: hipcc --offload-arch=gfx950 -O3 -o lds_gather lds_gather.hip ; run: ./lds_gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -31,8 +32,10 @@ __global__ __launch_bounds__(1024) void gather(const uint4 *__restrict__ codes, 
         else c = __builtin_amdgcn_readlane((int)c, 0) + (lane >> 4);   // one row per 16-lane group, no LDS traffic
       }
       // 256 "codes" per quantizer slot, entry = SHARE * 16 B; 8192 / 16 = 512 entries of 16 B per b
-      const int per_b = 512 / SHARE;   // distinct entries available per b (LDS capacity)
-      const int idx = b * 512 + (c % per_b) * SHARE + (lane % SHARE);
+      const int per_b = 512 / (SHARE == 0 ? 1 : SHARE);   // distinct entries available per b (LDS capacity)
+      // SHARE == 0: every lane its own random 256-B row, but the 16 lanes of a group in 16 different
+      // 16-B columns (conflict-free if the bank is address bits [7:4] only)
+      const int idx = SHARE == 0 ? b * 512 + (c % 32) * 16 + (lane & 15) : b * 512 + (c % per_b) * SHARE + (lane % SHARE);
       const uint4 x = lds[idx];
       acc.x += x.x; acc.y ^= x.y; acc.z += x.z; acc.w ^= x.w;
     }
@@ -64,6 +67,7 @@ int main() {
            ms * 1e6 / winst * 2.4);
   };
   run(gather<1>, "own16B");
+  run(gather<0>, "owncol");
   run(gather<2>, "pair32B");
   run(gather<4>, "quad64B");
   run(gather<16>, "row256B");
