@@ -713,7 +713,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, pr.st));
     pr.use_mfma = mfma_assign_supported(s, k);
-    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, pr.packed, pr.st);
+    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, k, pr.packed, pr.st);
     pr.xs.alloc((size_t)n * s);
     GULON_UNSUPPORTED((long long)n * s >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items",
                       (long long)n * s);
@@ -832,7 +832,7 @@ GULON_API int32_t gulon_kmeans_assign(const gulon_dataset *ds, int32_t from, int
     DevBuf<int> da; da.upload(assignments, ds->n);
     PackedSlice packed;
     const bool mf = mfma_assign_supported(s, k);
-    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, packed, nullptr);
+    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, k, packed, nullptr);
     kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, rng_batch, da.p, nullptr, mf ? &packed : nullptr);
     da.download(assignments, ds->n);
     HIP_CHECK(hipDeviceSynchronize());
@@ -866,7 +866,7 @@ GULON_API int32_t gulon_kmeans_iterate(const gulon_dataset *ds, int32_t from, in
     HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)std::max(ds->n, 1)));   // one array reused (KMeans.scala:101)
     PackedSlice packed;
     const bool mf = iters > 0 && mfma_assign_supported(s, k);
-    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, packed, nullptr);
+    if (mf) pack_slice(ds->x.p, ds->n, ds->d, from, s, k, packed, nullptr);
     for (int it = 0; it < iters; it++) {
       kmeans_assign_dev(ws, ds->x.p, ds->n, ds->d, from, s, dc.p, k, 0, da.p, nullptr, mf ? &packed : nullptr);
       kmeans_update_dev(ws, ds->x.p, ds->n, ds->d, from, s, k, da.p, dc.p, nullptr);
@@ -962,7 +962,7 @@ static void pq_encode_range(const gulon_dataset *ds, int m, int k, const float *
       dc.upload(cents + (size_t)k * from[j], (size_t)k * s);
       HIP_CHECK(hipMemset(da.p, 0, sizeof(int) * (size_t)n));
       const bool mf = mfma_assign_supported(s, k);
-      if (mf) pack_slice(ds->x.p, n, ds->d, from[j], s, packed, nullptr);
+      if (mf) pack_slice(ds->x.p, n, ds->d, from[j], s, k, packed, nullptr);
       kmeans_assign_dev(ws, ds->x.p, n, ds->d, from[j], s, dc.p, k, 0, da.p, nullptr, mf ? &packed : nullptr);   // serial assign
       uint8_t *out = codes_out + (size_t)(j - j_begin) * bytes;
       if (width == 8) {                                                                   // Coder8: idx.toByte

@@ -46,7 +46,7 @@ struct KmeansWorkspace {
 };
 
 bool mfma_assign_supported(int s, int k);
-void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps, hipStream_t st);
+void pack_slice(const float *dX, int n, int ld, int from, int s, int k, PackedSlice &ps, hipStream_t st);
 void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float *dC, int k, int *d_assign,
                         hipStream_t st);
 

@@ -42,7 +42,7 @@ __global__ void pack_slice_kernel(const float *__restrict__ X, int n, int ld, in
   out[t0] = (row < n && e < s) ? X[(size_t)row * ld + from + e] : 0.f;
 }
 
-// A operands (-2*c), C-init offsets (+inf beyond k) and max |c|^2
+// A operands (-2*c), C-init offsets (1e38 beyond k) and max |c|^2
 __global__ void pack_centroids_kernel(const float *__restrict__ C, const float *__restrict__ off, int k, int s, int T,
                                       int nkb, float *__restrict__ apack, float *__restrict__ offp,
                                       unsigned *__restrict__ cmax2_bits) {
@@ -53,7 +53,9 @@ __global__ void pack_centroids_kernel(const float *__restrict__ C, const float *
     apack[t0] = (c < k && e < s) ? -2.0f * C[(size_t)c * s + e] : 0.f;
   }
   if (t0 < nkb * 32) {
-    float o = t0 < k ? off[t0] : INFINITY;
+    // padding centroids (last block): a huge FINITE offset -- never the minimum, and its key stays a
+    // number (+inf with an index in the mantissa would be a NaN and flag every row through the band)
+    float o = t0 < k ? off[t0] : 1.0e38f;
     offp[t0] = o;
     if (t0 < k && o == o && o < INFINITY) atomicMax(cmax2_bits, __float_as_uint(o));
   }
@@ -198,16 +200,163 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
   }
 }
 
-bool mfma_assign_supported(int s, int k) {
-  if (getenv("GULON_KMEANS_NO_MFMA")) return false;
-  int T = (s + 1) / 2;
-  int nkb = (k + 31) / 32;
-  size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
-  return s >= 1 && T <= 8 && lds <= 60 * 1024;
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for long sub-vectors and/or many centroids (coarse clustering of whole
+// vectors: s = d = 128, k = n / 1000): the A operands no longer fit LDS, so every workgroup walks
+// the centroid blocks with a double-buffered 32-centroid A block (T*64 floats) shared by its four
+// waves, while each wave keeps the B operands of its tile pair (2*T floats per lane) in registers.
+// Per centroid block a wave issues 2*T MFMAs against one scan epilogue, so the matrix pipe
+// dominates (T = 64: 128 MFMAs = 8192 cycles vs ~400 cycles of VALU).  Same error band, same
+// flagged-row protocol, same output as assign_mfma<T>.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void assign_mfma_stream(const float *__restrict__ xq, int n, long long npairs,
+                                                          const float *__restrict__ apack,
+                                                          const float *__restrict__ offp, int nkb,
+                                                          const unsigned *__restrict__ cmax2_bits, float errk,
+                                                          int *__restrict__ assign, int *__restrict__ flag_rows,
+                                                          unsigned *__restrict__ flag_count) {
+  extern __shared__ float sm[];
+  constexpr int ABLK = T * 64;           // A operands of one centroid block
+  constexpr int BUF = ABLK + 32;         // + its 32 offsets
+  constexpr int PER = (BUF + 255) / 256; // floats staged per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;
+  const float cmax2 = __uint_as_float(*cmax2_bits);
+  float stage[PER];
+  auto fetch = [&](int kb) {             // global -> registers (block kb's A operands and offsets)
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int e = tid + u * 256;
+      stage[u] = e < ABLK ? apack[(size_t)kb * ABLK + e] : e < BUF ? offp[(size_t)kb * 32 + (e - ABLK)] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {           // registers -> LDS buffer
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int e = tid + u * 256;
+      if (e < BUF) sm[buf * BUF + e] = stage[u];
+    }
+  };
+  const long long ngroups = (npairs + 3) / 4;
+  for (long long pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
+    const long long pp = pg * 4 + wave;
+    const bool have_pair = pp < npairs;
+    float bx[T], by[T];
+    {
+      const float *px = xq + (size_t)(2 * (have_pair ? pp : npairs - 1)) * T * 64 + lane;   // clamped: always valid
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        bx[t] = px[(size_t)t * 64];
+        by[t] = px[(size_t)(T + t) * 64];
+      }
+    }
+    float nx = 0.f, ny = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; t++) { nx += bx[t] * bx[t]; ny += by[t] * by[t]; }
+    {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(nx), __float_as_uint(ny), false, false);
+      nx = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const float e2 = errk * (cmax2 + 2.0f * __fsqrt_rn(nx * cmax2)) + 1e-30f;
+    float pmin = FLT_MAX, mband = INFINITY;
+    int best = -1;
+
+    __syncthreads();                     // the previous group's last block is no longer read
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; kb++) {
+      const float *sA = sm + (kb & 1) * BUF;
+      if (kb + 1 < nkb) fetch(kb + 1);   // in flight during this block's MFMAs
+      f32x16 ax, ay;
+      {
+        const float4 *so = reinterpret_cast<const float4 *>(sA + ABLK + 4 * half);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const float4 o = so[2 * g];    // centroids 8g + 4*half + (0..3)
+          ax[4 * g + 0] = o.x; ax[4 * g + 1] = o.y; ax[4 * g + 2] = o.z; ax[4 * g + 3] = o.w;
+          ay[4 * g + 0] = o.x; ay[4 * g + 1] = o.y; ay[4 * g + 2] = o.z; ay[4 * g + 3] = o.w;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const float a = sA[t * 64 + lane];
+        ax = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bx[t], ax, 0, 0, 0);
+        ay = __builtin_amdgcn_mfma_f32_32x32x2f32(a, by[t], ay, 0, 0, 0);
+      }
+      // scan epilogue: identical to assign_mfma<T>::scan_block
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
+        ax[r] = __uint_as_float(sw[0]);
+        ay[r] = __uint_as_float(sw[1]);
+      }
+      unsigned key[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const float v = ((j >> 2) & 1) ? ay[4 * (j >> 3) + (j & 3)] : ax[4 * (j >> 3) + (j & 3)];
+        key[j] = (__float_as_uint(v) & ~31u) | (unsigned)j;
+      }
+      const float qbefore = pmin;
+#pragma unroll
+      for (int j = 0; j < 32; j += 2) {
+        const float k0 = __uint_as_float(key[j]), k1 = __uint_as_float(key[j + 1]);
+        float q0, q1;
+        asm("v_min_f32 %0, %1, %2" : "=v"(q0) : "v"(pmin), "v"(k0));
+        asm("v_min_f32 %0, %1, %2" : "=v"(q1) : "v"(q0), "v"(k1));
+        const float d0 = k0 - pmin, d1 = k1 - q0;
+        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
+        pmin = q1;
+      }
+      if (__float_as_uint(pmin) != __float_as_uint(qbefore)) best = kb * 32 + (int)(__float_as_uint(pmin) & 31u);
+      if (kb + 1 < nkb) commit((kb + 1) & 1);   // the other buffer was last read during block kb-1
+      __syncthreads();
+    }
+
+    const long long row = pp * 64 + lane;
+    const bool in_range = have_pair && row < n;
+    const bool my_amb = !(mband > e2);   // also true when mband is NaN
+    const bool flagged = in_range && (my_amb || best < 0 || !(e2 < INFINITY) || !(fabsf(pmin) < INFINITY));
+    if (in_range && !flagged) assign[row] = best;
+    const unsigned long long fm = __ballot(flagged);
+    if (fm) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(flag_count, (unsigned)__popcll(fm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (flagged) flag_rows[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)row;
+    }
+  }
 }
 
-void pack_slice(const float *dX, int n, int ld, int from, int s, PackedSlice &ps, hipStream_t st) {
-  ps.n = n; ps.from = from; ps.s = s; ps.T = (s + 1) / 2;
+// K-steps of the kernel that handles (s, k): the resident-A kernel when all A operands fit LDS and
+// s <= 16, else the streaming kernel with T rounded up to 16 / 32 / 64 (zero padding is exact);
+// 0 = not supported (s > 128)
+int mfma_kernel_T(int s, int k) {
+  if (s < 1) return 0;
+  const int T = (s + 1) / 2;
+  const int nkb = (k + 31) / 32;
+  const size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
+  if (T <= 8 && lds <= 60 * 1024) return T;
+  if (T <= 16) return 16;
+  if (T <= 32) return 32;
+  if (T <= 64) return 64;
+  return 0;
+}
+static bool mfma_streams(int s, int k) {
+  const int T = (s + 1) / 2;
+  const int nkb = (k + 31) / 32;
+  const size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
+  return !(T <= 8 && lds <= 60 * 1024);
+}
+
+bool mfma_assign_supported(int s, int k) {
+  if (getenv("GULON_KMEANS_NO_MFMA")) return false;
+  return mfma_kernel_T(s, k) != 0;
+}
+
+void pack_slice(const float *dX, int n, int ld, int from, int s, int k, PackedSlice &ps, hipStream_t st) {
+  ps.n = n; ps.from = from; ps.s = s; ps.T = mfma_kernel_T(s, k);
   long long ntile = ((long long)n + 31) / 32;
   ntile = (ntile + 1) / 2 * 2;   // whole pairs
   long long total = ntile * ps.T * 64;
@@ -225,6 +374,7 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
                         hipStream_t st) {
   const int s = ps.s, T = ps.T, n = ps.n;
   const int nkb = (k + 31) / 32;
+  GULON_REQUIRE(T == mfma_kernel_T(s, k), "packed slice was laid out for another kernel (T = %d)", T);
   ws.apack.ensure((size_t)nkb * T * 64);
   ws.offp.ensure((size_t)nkb * 32);
   ws.cmax2.ensure(1);
@@ -242,6 +392,17 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
   size_t lds = ((size_t)nkb * T * 64 + (size_t)nkb * 64) * sizeof(float);
   int grid = (int)std::min<long long>((npairs + 3) / 4, 256 * 8);
   if (grid < 1) grid = 1;
+  if (mfma_streams(s, k)) {
+    const size_t slds = 2 * ((size_t)T * 64 + 32) * sizeof(float);
+    const int sgrid = (int)std::max<long long>(1, std::min<long long>((npairs + 3) / 4, 256 * 2));
+#define AS(TT)                                                                                                     \
+    hipLaunchKernelGGL(assign_mfma_stream<TT>, dim3(sgrid), dim3(256), slds, st, ps.xq.p, n, npairs, ws.apack.p,    \
+                       ws.offp.p, nkb, ws.cmax2.p, errk, d_assign, ws.flag_rows.p, ws.flag_count.p)
+    if (T == 16) AS(16); else if (T == 32) AS(32); else AS(64);
+#undef AS
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
 #define AM(TT)                                                                                                   \
   hipLaunchKernelGGL(assign_mfma<TT>, dim3(grid), dim3(256), lds, st, ps.xq.p, n, npairs, ws.apack.p, ws.offp.p, \
                      nkb, ws.cmax2.p, errk, d_assign, ws.flag_rows.p, ws.flag_count.p)

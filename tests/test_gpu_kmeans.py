@@ -154,3 +154,26 @@ def test_index_sorted_end_to_end(oracle, g):
         assert np.array_equal(bits(r.distances), bits(od[q]))
         if r.flags == 0:
             assert r.rows.tolist() == oi[q].tolist()
+
+
+@pytest.mark.parametrize("n,d,frm,s,k,seed", [
+    (20000, 40, 4, 33, 70, 2),        # T = 17 -> streaming kernel with 32 K-steps
+    (15000, 128, 0, 128, 300, 4),     # coarse clustering shape: whole 128-d vectors, T = 64
+    (30000, 8, 0, 8, 3000, 6),        # short sub-vectors but too many centroids for LDS: T padded to 16
+    (9000, 70, 3, 64, 33, 8),         # T = 32, k not a multiple of 32
+    (6000, 24, 0, 24, 40, 10),        # duplicated rows and centroids: ties go through the exact path
+])
+def test_streaming_mfma_assign_bit_exact(oracle, g, n, d, frm, s, k, seed):
+    """Long sub-vectors / many centroids use assign_mfma_stream (A operands streamed through LDS)."""
+    X = _clustered(seed, n, d)
+    if seed == 10:
+        X[n // 2:] = X[:n - n // 2]
+    dm = g.DeviceMatrix.from_host(X)
+    v = g.Vectors(dm, frm, frm + s)
+    km = g.KMeans.init(k, v, seed)           # init draws rows with replacement: duplicate centroids happen
+    C0, _ = oracle.kmeans_init(X, frm, s, k, seed)
+    assert np.array_equal(bits(km.centroids), bits(C0))
+    for rb, fn in ((0, km.assign), (25000, km.par_assign)):
+        assert np.array_equal(fn(v), oracle.kmeans_assign(X, frm, s, C0, rb))
+    it = km.iterate(v, 2)
+    assert np.array_equal(bits(it.centroids), bits(oracle.kmeans_iterate(X, frm, s, C0, 2)))
