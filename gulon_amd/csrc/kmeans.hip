@@ -215,6 +215,62 @@ __global__ __launch_bounds__(256) void assign_resolve(const float *__restrict__ 
   if (best >= 0) assign[i] = best;
 }
 
+// The same replay with one WAVE per drawing row (for many centroids / long sub-vectors, where one
+// thread walking k * s products is a 100-ms latency chain): rows with draws are compacted first;
+// the lanes compute 64 centroids' distances at a time (each lane its centroid's sequential,
+// unfused chain -- the reference's arithmetic), then the scan over those 64 runs in centroid order
+// on the candidates that can change the minimum or draw (d <= running minimum).
+__global__ void collect_tie_rows(const unsigned *__restrict__ ties, const int *__restrict__ rows, int nrows,
+                                 int *__restrict__ list, unsigned *__restrict__ count) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nrows) return;
+  int i = rows ? rows[t] : t;
+  if (ties[i] != 0) list[atomicAdd(count, 1u)] = i;
+}
+
+__global__ __launch_bounds__(64) void assign_resolve_wave(const float *__restrict__ X, int ld, int from, int s,
+                                                          const float *__restrict__ Cpad, int smax,
+                                                          const float *__restrict__ off, int k,
+                                                          const unsigned *__restrict__ local,
+                                                          const unsigned long long *__restrict__ block_off,
+                                                          int seg_len, int bps, const int *__restrict__ list,
+                                                          const unsigned *__restrict__ count,
+                                                          int *__restrict__ assign) {
+  extern __shared__ float rowv[];   // s
+  const int lane = threadIdx.x;
+  const unsigned total = *count;
+  for (unsigned e = blockIdx.x; e < total; e += gridDim.x) {
+    const int i = list[e];
+    __syncthreads();
+    for (int j = lane; j < s; j += 64) rowv[j] = X[(size_t)i * ld + from + j];
+    __syncthreads();
+    const int seg = i / seg_len;
+    const int blk = (i - seg * seg_len) / 1024;
+    JRandom rng(0);
+    rng.skip(block_off[(size_t)seg * bps + blk] + local[i]);
+    float mn = FLT_MAX;
+    int best = -1;
+    for (int c0 = 0; c0 < k; c0 += 64) {
+      const int c = c0 + lane;
+      float d = 0.f;
+      if (c < k) {
+        const float *cc = Cpad + (size_t)c * smax;
+        for (int j = 0; j < s; j++) d += rowv[j] * cc[j];
+        d = off[c] - 2 * d;
+      }
+      // in centroid order: only d < mn or d == mn can act (NaN never does)
+      unsigned long long mk = __ballot(c < k && d <= mn);
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float dv = readlane_f(d, l);
+        if (dv < mn || (dv == mn && rng.next_boolean())) { best = c0 + l; mn = dv; }
+      }
+    }
+    if (lane == 0 && best >= 0) assign[i] = best;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // misc small kernels
 // ---------------------------------------------------------------------------
@@ -504,6 +560,18 @@ static void launch_tie_replay(AssignJob &j) {
   hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, j.st, ws.block_tot.p, bps, ws.block_off.p);
   const int *rows = j.filtered ? j.rows : nullptr;
   const int nrows = j.filtered ? j.nrows : n;
+  if ((long long)j.k * j.s >= 16384) {   // long per-row replays: one wave per drawing row
+    ws.tie_rows.ensure((size_t)std::max(nrows, 1));
+    ws.tie_count.ensure(1);
+    HIP_CHECK(hipMemsetAsync(ws.tie_count.p, 0, sizeof(unsigned), j.st));
+    hipLaunchKernelGGL(collect_tie_rows, dim3(ceil_div(nrows, 256)), dim3(256), 0, j.st, ws.ties.p, rows, nrows,
+                       ws.tie_rows.p, ws.tie_count.p);
+    hipLaunchKernelGGL(assign_resolve_wave, dim3(1024), dim3(64), sizeof(float) * (size_t)j.s, j.st, j.dX, j.ld, j.from,
+                       j.s, ws.cpad.p, smax, ws.off.p, j.k, ws.local.p, ws.block_off.p, seg_len, bps, ws.tie_rows.p,
+                       ws.tie_count.p, j.d_assign);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(assign_resolve<0>, dim3(ceil_div(nrows, 256)), dim3(256), 0, j.st, j.dX, n, j.ld, j.from, j.s,
                      ws.cpad.p, smax, ws.off.p, j.k, ws.ties.p, ws.local.p, ws.block_off.p, seg_len, bps, rows, nrows,
                      j.d_assign);
