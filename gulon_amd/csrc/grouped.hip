@@ -6,17 +6,21 @@
 //                 Result.fromHeap(heap)
 //
 // The per-group heaps are merged with TopKHeap.merge, i.e. update() of the other heap's slots in
-// ARRAY order, so under distance ties the answer depends on the literal heaps.  Groups are short
-// (n / #groups rows), so the GPU path simply runs the reference's algorithm literally:
-//   gq_coarse       one wave per query: centroid distances 64 at a time, literal TopKHeap in
-//                   registers (lane = slot) for LimitGroups; (distance, id) sort for LimitVectors
-//   gq_group_scan   one wave per (query, searched group): the residual's m x k table is built in
-//                   LDS (Index.prepareQuery arithmetic), the group's rows are scored 64 at a time
-//                   (PQIndex.distances order) and pushed, in row order, through a literal TopKHeap;
-//                   the heap is stored in array order
-//   gq_merge        one wave per query: TopKHeap.merge of the group heaps in search order, then
-//                   Result.fromHeap
-// No tie flags and no replay are needed here: the literal heaps ARE the reference semantics.
+// ARRAY order, so under distance ties the answer depends on the literal heaps.  Kernels:
+//   gq_cdist            query x centroid distances (MathUtils.distanceSq order), centroids transposed
+//   gq_nearest_groups   LimitGroups(<= 63): literal TopKHeap in registers (lane = slot) + deleteAll
+//   gq_sorted_groups    LimitVectors / larger limits: (distance, id) bitonic sort, cut by rows or count
+//   gq_group_scan       workgroup = 4 (query, searched group) pairs, one wave each: the residual's
+//                       m x k table in LDS (Index.prepareQuery arithmetic; each quantizer's codebook
+//                       staged once per workgroup, transposed), then the group's rows 64 at a time
+//                       (PQIndex.distances order).  Two instantiations:
+//                         fast     ascending (distance, row) list of K+1 entries per pair
+//                         literal  the reference's TopKHeap, fed in row order, stored in array order
+//   gq_merge_fast       merges the lists; a query whose K+1 best contain equal distances (or that
+//                       saw a NaN) is appended to a list ...
+//   gq_group_scan<literal> + gq_merge   ... and redone literally: TopKHeap.merge of the group heaps
+//                       in search order + Result.fromHeap.  Ids and order therefore equal the
+//                       reference's also under ties (GULON_GROUPED_LITERAL=1: every query).
 #include "scan.hpp"
 
 using gulon::DevBuf;
