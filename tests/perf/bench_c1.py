@@ -1,12 +1,12 @@
 """BASELINE config 1: 100k x 50 random vectors, exact L2 top-10 (Index.exactNearestNeighbours):
-GPU kernel vs the CPU oracle on the same queries.  python scripts/bench_c1.py"""
+GPU kernel vs the CPU oracle on the same queries.  python tests/perf/bench_c1.py"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gulon_amd as g
 from gulon_amd.recall import sample_rows
 from oracle import oracle

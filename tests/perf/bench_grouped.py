@@ -1,6 +1,6 @@
 """GroupedIndex benchmark: coarse KMeans -> grouping -> residual PQ -> batched queries
 with the reference CLI's defaults (partitions = n / 1000, LimitGroups(max(5 % of partitions, 5)),
-BuildIndex.scala:104-106).   python scripts/bench_grouped.py [rows] [dim] [partitions] [limit]"""
+BuildIndex.scala:104-106).   python tests/perf/bench_grouped.py [rows] [dim] [partitions] [limit]"""
 import ctypes as C
 import json
 import os
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import gulon_amd as g
 from gulon_amd import native as N
