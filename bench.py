@@ -145,6 +145,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enqueue_s = time.perf_counter() - t_start          # host time to enqueue K steps (diagnostic)
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -196,6 +197,7 @@ def main():
                      "kernel_ms": scan_ms, "launches_per_step": launches.value / max(args.steps, 1),
                      "algorithmic_bytes_per_launch": alg_bytes},
         "build_seconds": build_s,
+        "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
     }
 
     if rank == 0:
