@@ -44,6 +44,11 @@ class HipEngine:
     def __init__(self, pq, shard: EncodedMatrix, row_base, device):
         import torch
         from .index import PQIndex
+        # torch's HIP runtime has to come up BEFORE libgulon_hip.so touches the device in this process
+        # (the other order leaves torch with "No HIP GPUs are available"): bench.py calls
+        # torch.cuda.set_device first; do the same in any process that mixes the two.
+        if not torch.cuda.is_initialized():
+            torch.cuda.init()
         self.torch = torch
         self.device = device
         self.index = PQIndex(pq, shard, row_base=row_base)

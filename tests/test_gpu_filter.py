@@ -208,3 +208,62 @@ def test_randomised_shapes_against_the_oracle(oracle, g, tune):
         except AssertionError as e:
             raise AssertionError(f"case {case}: n={n} d={d} m={m} k={k} B={B} K={K} dup={dup} range=[{frm},{until})") from e
         ix.close()
+
+
+def _two_streams_worker(out):
+    """Runs in a fresh process with torch initialised first (the order bench.py uses: torch's HIP
+    runtime does not come up after libgulon_hip.so has initialised the device)."""
+    import ctypes as C
+    import os
+    import sys
+    import torch
+    torch.cuda.init()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gulon_amd as g
+    from gulon_amd import native as N
+    from oracle import oracle
+    from test_gpu_query import _make
+    n, d, m, k, B, K = 300000, 64, 16, 256, 96, 10           # default thresholds: the filter is active
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=77)
+    rng = np.random.default_rng(9)
+    Qs = [rng.standard_normal((B, d)).astype(np.float32) for _ in range(2)]
+    exp = [oracle.pq_batch_query(idx, d, k, cents, q, K) for q in Qs]
+    ixs = [g.PQIndex(pq, enc) for _ in range(2)]
+    dq = [torch.from_numpy(q).cuda() for q in Qs]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [[torch.empty((B, K), dtype=torch.int32, device="cuda"), torch.empty((B, K), dtype=torch.float32, device="cuda"),
+             torch.empty(B, dtype=torch.int32, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda")]
+            for _ in range(2)]
+    torch.cuda.synchronize()
+    L = N.lib()
+    for rep in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                oi, od, oc, of = outs[i]
+                N.check(L.gulon_index_batch_query_dev(ixs[i]._h, dq[i].data_ptr(), B, K, 0, n, oi.data_ptr(), od.data_ptr(),
+                                                      oc.data_ptr(), of.data_ptr(),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ok = True
+    for i in range(2):
+        oi, od, oc, of = (t.cpu().numpy() for t in outs[i])
+        ei, ed, ec = exp[i]
+        ok = ok and np.array_equal(od.view(np.uint32), ed.view(np.uint32)) and np.array_equal(oc, ec)
+        for q in range(B):
+            if of[q] == 0 or (of[q] & 4):
+                ok = ok and oi[q].tolist() == ei[q].tolist()
+    out.put(1 if ok else 0)
+
+
+def test_two_batches_in_flight_on_two_streams():
+    """Two indexes over the same rows, two streams, calls interleaved without synchronising in
+    between (what bench.py does): the turn-taking of the main filter stage must not mix results."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_two_streams_worker, args=(out,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert out.get(timeout=5) == 1
