@@ -7,7 +7,7 @@
 //
 //   1. the exact distances of a few thousand strided sample rows give every query a valid upper
 //      bound tau on its final (K+1)-th distance (the (K+1)-th smallest of a subset);
-//   2. per query the fp32 table T_j[c] is quantized DOWNWARDS:
+//   2. per query the fp32 table T_j[c] is quantized DOWNWARDS (min_j comes out of build_tables):
 //        q_j[c] = min(QMAX, floor((T_j[c] - min_j) / delta)),  delta = (tau' - sum_j min_j) / QL,
 //      where tau' = tau * (1 + 2 m u), u = 2^-24, covers the rounding of the reference's
 //      sequential fp32 sum D against the real sum R (all terms >= 0: D >= R (1 - m u)).
@@ -43,25 +43,13 @@ __device__ inline float table_at(const float *__restrict__ tables, int W, int m_
   return tables[(((size_t)(q / W) * m_pad + j) * 256 + c) * W + q % W];
 }
 
-// ---- per (query, quantizer) minimum of the fp32 table (NaN entries ignored) ----------------
-__global__ __launch_bounds__(256) void qt_mins(const float *__restrict__ tables, int W, int Bp, int m_pad, int k,
-                                               float *__restrict__ mins) {
-  __shared__ unsigned smin[16];
-  const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
-  if (c < 16) smin[c] = 0x7F800000u;
-  __syncthreads();
-#pragma unroll 4
-  for (int u = 0; u < 16; u++) {
-    const int q = g16 * 16 + u;
-    float x = INFINITY;
-    if (q < Bp && c < k) x = table_at(tables, W, m_pad, q, j, c);
-    x = x != x ? INFINITY : x;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
-    if ((c & 63) == 0) atomicMin(&smin[u], __float_as_uint(x));   // entries are >= +0: uint order
-  }
-  __syncthreads();
-  if (c < 16) mins[(size_t)(g16 * 16 + c) * m_pad + j] = __uint_as_float(smin[c]);
+// ---- per-batch reset of the small scratch arrays in one launch ----------------------------------
+__global__ void filter_reset(unsigned *__restrict__ gtau, int n_gtau, int *__restrict__ fb_tile, int n_fb,
+                             int *__restrict__ sv_cnt, int n_cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_gtau) gtau[t] = 0x7F800000u;   // +inf
+  if (t < n_fb) fb_tile[t] = 0;
+  if (t < n_cnt) sv_cnt[t] = 0;
 }
 
 // ---- quantize the tables of one 16-query group against the current bounds --------------------
@@ -598,11 +586,16 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   ix->sv_queue.ensure((size_t)Bq * NSLOT * cap);
   ix->fb_tile.ensure((size_t)ntiles);
   ix->tau0.ensure((size_t)Bp);
-  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ix->gtau.p, 0x7F800000 /* +inf */, (size_t)Bp, st));
-  HIP_CHECK(hipMemsetAsync(ix->fb_tile.p, 0, sizeof(int) * (size_t)ntiles, st));
-  HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Bq * NSLOT, st));
+  {
+    const int most = std::max(std::max(Bp, ntiles), Bq * NSLOT);
+    hipLaunchKernelGGL(filter_reset, dim3(ceil_div(most, 256)), dim3(256), 0, st, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,
+                       ix->sv_cnt.p, Bq * NSLOT);
+    HIP_CHECK(hipGetLastError());
+  }
 
-  launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st);
+  // the table minima of the B real queries come out of the table build; the padding queries of the
+  // last 16-query quantisation group are dead and never read theirs
+  launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st, nullptr, ix->qmins.p);
   {   // bounds from a strided sample of about filter_sample rows; resets the running lists
     // sample size ~ sqrt(rows): the sample scan costs ~1.4 us per 1000 rows, the first filter
     // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
@@ -625,10 +618,6 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 #undef BS
     HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(qt_mins, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st, ix->tables.p, W, Bp, ix->m_pad, ix->k,
-                     ix->qmins.p);
-  HIP_CHECK(hipGetLastError());
-
   const bool stats = getenv("GULON_FILTER_STATS") != nullptr;
   for (int sidx = 0; sidx < 3; sidx++) {
     const RbMap mp = stages[sidx];

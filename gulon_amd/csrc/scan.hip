@@ -68,8 +68,10 @@ template <bool INTERLEAVED, int W>
 __global__ void build_tables(const float *__restrict__ cents, const int *__restrict__ from,
                              const int *__restrict__ sdim, int d, int m, int k, int m_pad,
                              const float *__restrict__ Q, int B, float *__restrict__ T,
-                             const int *__restrict__ live_queries) {
-  // one thread per (query group of W, quantizer, centroid)
+                             const int *__restrict__ live_queries, float *__restrict__ mins) {
+  // one thread per (query group of W, quantizer, centroid); a block of 256 threads = the 256
+  // centroids of ONE (query group, quantizer), so the per-(query, quantizer) table minimum the
+  // quantized filter needs (NaN entries ignored) is a block reduction here (mins != nullptr)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (live_queries) B = min(B, *live_queries);   // device-side query count (tie replay: usually 0)
   int nqg = (B + W - 1) / W;
@@ -95,6 +97,20 @@ __global__ void build_tables(const float *__restrict__ cents, const int *__restr
         }
       }
     }
+  }
+  if (INTERLEAVED && mins != nullptr) {
+    __shared__ unsigned smin[W];
+    if (threadIdx.x < W) smin[threadIdx.x] = 0x7F800000u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      float x = (c < k && acc[u] == acc[u]) ? acc[u] : INFINITY;   // entries beyond k are not real table entries
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+      if ((threadIdx.x & 63) == 0) atomicMin(&smin[u], __float_as_uint(x));   // entries are >= +0: uint order
+    }
+    __syncthreads();
+    if (threadIdx.x < W) mins[(size_t)(qg * W + threadIdx.x) * m_pad + j] = __uint_as_float(smin[threadIdx.x]);
   }
   if (INTERLEAVED) {
 #pragma unroll
@@ -464,12 +480,12 @@ void launch_peel_finalize(const float *pv, const int *pi, int B, int cap, int K,
 }
 
 void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
-                         const int *live_queries) {
+                         const int *live_queries, float *mins) {
   long long total = (long long)(Bpad / W) * ix->m_pad * 256;
   if (total <= 0) return;
 #define BT(WW)                                                                                             \
   hipLaunchKernelGGL((build_tables<true, WW>), dim3(ceil_div(total, 256)), dim3(256), 0, st, ix->cents.p,   \
-                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, tables, live_queries)
+                     ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->m_pad, dQ, B, tables, live_queries, mins)
   if (W == 4) BT(4); else if (W == 2) BT(2); else BT(1);
 #undef BT
   HIP_CHECK(hipGetLastError());
@@ -931,7 +947,7 @@ GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, 
     dc.upload(cents, (size_t)k * d); dq.upload(queries, (size_t)b * d);
     long long total = (long long)((b + 3) / 4) * m * 256;
     hipLaunchKernelGGL((build_tables<false, 4>), dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
-                       m, dq.p, b, dt.p, (const int *)nullptr);
+                       m, dq.p, b, dt.p, (const int *)nullptr, (float *)nullptr);
     HIP_CHECK(hipGetLastError());
     dt.download(t_out, (size_t)b * m * k);
     HIP_CHECK(hipDeviceSynchronize());

@@ -130,7 +130,7 @@ __device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
 
 // Index.prepareQuery tables, W queries interleaved (scan.hip)
 void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
-                         const int *live_queries = nullptr);
+                         const int *live_queries = nullptr, float *mins = nullptr);
 // For every query flagged with an exact distance tie, recompute the result with the
 // reference's TopKHeap semantics (insertion history in row order) -- replay.hip
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
