@@ -501,14 +501,18 @@ struct FilterLane {
 FilterLane &filter_lane() { static FilterLane l; return l; }
 
 // queries per quantized table entry: as many as LDS holds for one group (16 up to m_pad = 36,
-// 8 up to 72, 4 up to 144), and how many such groups a workgroup takes (2 if they fit)
+// 8 up to 72, 4 up to 144) ...
 int filter_qw(const gulon_index *ix) {
   int qw = 16;
   while (qw > 4 && (size_t)ix->m_pad * 256 * qw > FILTER_LDS_BUDGET) qw /= 2;
   return qw;
 }
+// ... and how many such groups a workgroup takes: two only if two workgroups of that size still
+// fit a CU's 160 KiB -- two resident workgroups hide each other's table staging and barriers
+// (measured at m = 16: 3.18 -> 3.01 ms for the main stage against one workgroup with two groups)
 int filter_nqg(const gulon_index *ix) {
-  return (size_t)ix->m_pad * 256 * filter_qw(ix) * 2 <= FILTER_LDS_BUDGET ? 2 : 1;
+  if (const char *e = getenv("GULON_FILTER_NQG")) { int v = atoi(e); if (v == 1 || v == 2) return v; }   // experiment knob
+  return (size_t)ix->m_pad * 256 * filter_qw(ix) * 4 <= 160 * 1024 ? 2 : 1;
 }
 
 void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
