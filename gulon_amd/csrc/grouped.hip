@@ -32,7 +32,7 @@ struct gulon_grouped_index {
   DevBuf<int> bounds;              // [g+1] first row of every group, then n
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
-  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount;
+  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok;
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
 };
@@ -140,8 +140,10 @@ __global__ __launch_bounds__(64) void gq_nearest_groups(const float *__restrict_
 // sort in LDS.
 __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict__ cdist, int g, int n2,
                                                         const int *__restrict__ bounds, int by_vectors, int limit,
-                                                        int *__restrict__ nn, int stride, int *__restrict__ nn_cnt) {
+                                                        int *__restrict__ nn, int stride, int *__restrict__ nn_cnt,
+                                                        const int *__restrict__ done) {
   extern __shared__ float gs_lds[];
+  if (done && done[blockIdx.x]) return;   // gq_select_groups already answered this query
   float *sv = gs_lds;
   int *si = reinterpret_cast<int *>(gs_lds + n2);
   const int q = blockIdx.x, tid = threadIdx.x;
@@ -177,6 +179,84 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
   __syncthreads();
   const int cnt = nn_cnt[q];
   for (int e = tid; e < cnt; e += 256) nn[(size_t)q * stride + e] = si[e];
+}
+
+// LimitGroups(limit) for limit > 63 (the CLI's default is 5 % of the groups): only the `limit` nearest
+// centroids are needed, so instead of sorting all g distances the limit-th smallest key is found
+// by a 4-pass radix select on the float bits (distances are >= +0: unsigned order), everything at or
+// below it is compacted (limit + ties entries) and only that is sorted by (distance, id).
+// ok[q] = 0 if more than `cap` entries tie at the threshold (the caller then sorts everything).
+__global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict__ cdist, int g, int limit, int cap,
+                                                        int *__restrict__ nn, int stride,
+                                                        int *__restrict__ nn_cnt, int *__restrict__ ok) {
+  extern __shared__ float sel_lds[];
+  float *sv = sel_lds;                                     // [cap]
+  int *si = reinterpret_cast<int *>(sel_lds + cap);        // [cap]
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_remaining;
+  __shared__ int s_count;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float *dq = cdist + (size_t)q * g;
+  auto keyof = [&](int c) { const float v = dq[c]; return v != v ? 0x7F800000u : __float_as_uint(v); };   // NaN orders last
+  const int want = min(limit, g);
+  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)want; s_count = 0; }
+  __syncthreads();
+  unsigned mask = 0u;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int c = tid; c < g; c += 256) {
+      const unsigned key = keyof(c);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rem = s_remaining, cum = 0u;
+      int b = 0;
+      for (; b < 255; b++) {
+        if (cum + hist[b] >= rem) break;
+        cum += hist[b];
+      }
+      s_remaining = rem - cum;
+      s_prefix = prefix | ((unsigned)b << shift);
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const unsigned thr = s_prefix;                           // key of the want-th smallest distance
+  for (int c = tid; c < g; c += 256) {
+    const unsigned key = keyof(c);
+    if (key <= thr) {
+      const int p = atomicAdd(&s_count, 1);
+      if (p < cap) { sv[p] = __uint_as_float(key); si[p] = c; }
+    }
+  }
+  __syncthreads();
+  const int cnt = s_count;
+  if (cnt > cap) {                                         // a huge tie at the threshold
+    if (tid == 0) ok[q] = 0;
+    return;
+  }
+  int n2 = 64;
+  while (n2 < cnt) n2 <<= 1;
+  for (int e = cnt + tid; e < n2; e += 256) { sv[e] = INFINITY; si[e] = INT_MAX; }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      for (int i = tid; i < n2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float a = sv[i], b = sv[l];
+          const int ai = si[i], bi = si[l];
+          const bool gt = a > b || (a == b && ai > bi);
+          if (gt == ((i & k) == 0)) { sv[i] = b; sv[l] = a; si[i] = bi; si[l] = ai; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int e = tid; e < want; e += 256) nn[(size_t)q * stride + e] = si[e];
+  if (tid == 0) { nn_cnt[q] = want; ok[q] = 1; }
 }
 
 // ---- one searched group of one query -------------------------------------------------------------
@@ -450,8 +530,21 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     GULON_UNSUPPORTED(lds > 144 * 1024, "%d groups: ordering all of them needs %zu B of LDS (> 144 KiB)", g, lds);
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_sorted_groups),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int *done = nullptr;
+    if (strategy == 0 && limit >= 1 && limit * 4 <= g) {
+      // few of many: radix-select + sort of the selected; the full sort only runs for queries it gave up on
+      int cap = 256;
+      while (cap < limit + 128) cap <<= 1;
+      gx->sel_ok.ensure((size_t)B);
+      const size_t sel_lds = (size_t)cap * 8;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_select_groups),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+      hipLaunchKernelGGL(gq_select_groups, dim3(B), dim3(256), sel_lds, st, gx->cdist.p, g, limit, cap, gx->nn.p,
+                         nn_stride, gx->nn_cnt.p, gx->sel_ok.p);
+      done = gx->sel_ok.p;
+    }
     hipLaunchKernelGGL(gq_sorted_groups, dim3(B), dim3(256), lds, st, gx->cdist.p, g, n2, gx->bounds.p, strategy == 1,
-                       limit, gx->nn.p, nn_stride, gx->nn_cnt.p);
+                       limit, gx->nn.p, nn_stride, gx->nn_cnt.p, done);
     if (strategy == 1 && nn_stride > 64) {
       // LimitVectors rarely needs more than a handful of groups: size the per-group heaps by the
       // largest count of this batch (one small read-back) instead of by the worst case

@@ -111,3 +111,22 @@ def test_bad_arguments(g):
     gc = np.zeros(2 * 8, np.float32)
     off = np.array([20], np.int32)                       # beyond n = 10
     assert N.lib().gulon_grouped_index_create(codes, 10, 8, 4, 256, cents, gc, off, 2, C.byref(h)) == -1
+
+
+@pytest.mark.parametrize("dup", [0, 2000])
+def test_many_groups_radix_select_of_the_nearest(oracle, g, dup):
+    """LimitGroups(70) of ~300 groups: the nearest groups come from the radix-select kernel
+    (limit > 63 and limit * 4 <= groups); with duplicated rows centroid distances can tie too."""
+    n, d, m, k, B, K = 24000, 16, 4, 16, 11, 10
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, 300, m, k, seed=31, dup=dup, iters=2)
+    assert len(gv.centroids) >= 4 * 70
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    index = g.Index.grouped(gv, pq, g.LimitGroups(70))
+    Q = X[np.random.default_rng(2).integers(0, n, B)]
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, 0, 70)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+    index.close()
