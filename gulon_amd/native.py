@@ -115,7 +115,7 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gulon_abi_version() != 1:
+        if L.gulon_abi_version() != 2:
             raise ImportError("libgulon_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GULON_ABI_VERSION 1
+#define GULON_ABI_VERSION 2
 
 #define GULON_OK 0
 #define GULON_ERR_INVALID_ARGUMENT (-1) /* reference: require(...) / IllegalArgumentException */
