@@ -47,6 +47,10 @@ def main():
                     help="query batches in flight (each on its own stream with its own scratch)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 on their own (RCCL's
+    # version banner at communicator creation does) are sent to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import gulon_amd as g
     from gulon_amd import native as N
@@ -65,7 +69,11 @@ def main():
     torch.cuda.set_device(local_rank)
     N.check(N.lib().gulon_set_device(local_rank))
     dist = None
-    if world > 1:
+    rehearse = world == 1 and bool(os.environ.get("GULON_BENCH_REHEARSE"))   # one rank, real RCCL calls
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+    if world > 1 or rehearse:
         import torch.distributed as dist
         if os.environ.get("GULON_BENCH_BACKEND") == "gloo":   # rehearsal of the multi-rank path on one GPU
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -105,8 +113,11 @@ def main():
     # one engine (= device index + scratch) and one stream per batch in flight
     nfl = max(1, args.inflight)
     engines = [HipEngine(pq, shard, lo, dev) for _ in range(nfl)]
-    shardeds = [ShardedIndex(e, n, rank, world, dist) for e in engines]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+    shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse) for e in engines]
+    if "GULON_BENCH_STREAM_PRIORITY" in os.environ:
+        streams = [torch.cuda.Stream(priority=int(os.environ["GULON_BENCH_STREAM_PRIORITY"])) for _ in range(nfl)]
+    else:
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
     engine, sharded, index = engines[0], shardeds[0], engines[0].index
     note("device index built")
     build_s = dict(synth=t1 - t0, train=t2 - t1, encode=t3 - t2)
@@ -199,6 +210,8 @@ def main():
         "build_seconds": build_s,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
     }
+    if rehearse:
+        result["config"]["rehearsal"] = "one rank through the multi-rank pipeline (RCCL all-gathers of one list)"
 
     if rank == 0:
         if not args.no_recall:
@@ -236,7 +249,8 @@ def main():
                     "sample": f"first {n_q} of the {B} queries over all {n} rows, single thread, "
                               f"4096-row blocks (Index.scala:424); C restatement of Gulon's JVM algorithm"}
                 result["parity_vs_oracle"] = {"queries": n_q, "distances_bit_exact": same_d, "ids_equal": same_i}
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

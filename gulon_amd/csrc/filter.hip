@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
                                                    const float *__restrict__ tau0, int keff, int qmax, int QW,
                                                    uint8_t *__restrict__ qtab /*[Bq/QW][m_pad][256][QW]*/,
                                                    int *__restrict__ fb_tile, int qt) {
-  __shared__ double s_delta[16];
+  __shared__ double s_delta[16], s_inv[16];
   __shared__ float s_min[16];
   __shared__ int s_dead[16];
   const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
     }
     s_dead[c] = dead;
     s_delta[c] = delta;
+    s_inv[c] = 1.0 / delta;
     s_min[c] = mins[(size_t)q * m_pad + j];
   }
   __syncthreads();
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
       if (have && !s_dead[s] && v == v) {
         double x = ((double)v - (double)s_min[s]) * (1.0 - 8.9e-16);
         if (x < 0.0) x = 0.0;
-        const double r = x / s_delta[s];
+        const double r = x * s_inv[s];                       // ~ x / delta; any level with level * delta <= x is valid
         if (r < (double)qmax) {
           qv = (int)r;                                       // floor: r >= 0
-          while (qv > 0 && (double)qv * s_delta[s] > x) qv--;   // guard the rounding of the division
+          while (qv > 0 && (double)qv * s_delta[s] > x) qv--;   // guard the rounding of the reciprocal
         }
       }
       word |= (uint32_t)qv << (8 * u);
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
                                                              const float *__restrict__ tables, int row_from,
                                                              int row_until, int rb_begin, int e_count, RbMap mp, int B,
                                                              int keff, float *__restrict__ tau0,
-                                                             float *__restrict__ fin_v, int *__restrict__ fin_i) {
+                                                             float *__restrict__ fin_v, int *__restrict__ fin_i,
+                                                             float *__restrict__ bounds_out) {
   constexpr int NW = FILTER_THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
   using TV = typename FTab<W>::type;
@@ -233,7 +235,44 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
     if (q < B) {
       if (lane == keff - 1) tau0[q] = best;          // +inf when fewer than K+1 groups saw a row
       if (lane < keff) { fin_v[(size_t)q * keff + lane] = INFINITY; fin_i[(size_t)q * keff + lane] = INT_MAX; }
+      if (bounds_out && lane < keff) bounds_out[(size_t)q * keff + lane] = best;   // for the other shards
     }
+  }
+}
+
+// ---- bounds shared across shards: tau0[q] = the keff-th smallest of the union of `lists` ascending
+// arrays of keff sample distances (one per shard, this shard's own among them).  Each of them belongs
+// to a distinct row of the whole index, so the value bounds the index-wide keff-th distance from above.
+// One wave per query; bisection over the ordered bit patterns (32 counting passes over <= 64 * lists values).
+__global__ __launch_bounds__(256) void shared_tau(const float *__restrict__ all /*[lists][B][keff]*/, int lists, int B,
+                                                  int keff, float *__restrict__ tau0) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= B) return;
+  const int n = lists * keff;
+  auto key_at = [&](int i) {
+    const int l = i / keff, e = i - l * keff;
+    const uint32_t u = __float_as_uint(all[((size_t)l * B + q) * keff + e]);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // unsigned order = float order
+  };
+  constexpr int R = 4;                                           // values per lane held in registers
+  uint32_t held[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) held[r] = lane + 64 * r < n ? key_at(lane + 64 * r) : 0xFFFFFFFFu;
+  uint32_t t = 0;
+  for (int bit = 31; bit >= 0; bit--) {
+    const uint32_t cand = t | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) c += held[r] < cand ? 1 : 0;
+    for (int i = lane + 64 * R; i < n; i += 64) c += key_at(i) < cand ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if (c < keff) t = cand;                                      // fewer than keff values below: go up
+  }
+  if (lane == 0) {
+    const float v = __uint_as_float((t & 0x80000000u) ? (t & 0x7FFFFFFFu) : ~t);
+    if (v == v) tau0[q] = fminf(tau0[q], v);
   }
 }
 
@@ -539,8 +578,10 @@ bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
 }
 
 void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
-                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
+                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st,
+                      const SharedBounds *sb) {
   const ScanTuning &t = tuning();
+  const int phase = sb ? sb->phase : 0;
   const int keff = K + 1;
   const int W = ix->w;               // fp32 table interleave of the exact kernels
   const int QT = W * ix->nsub;
@@ -561,15 +602,30 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   const int s0 = std::min(std::max(t.filter_stage0, 0), P - 2);
   const int s1 = std::min(std::max(t.filter_stage1, 1), P - 1 - s0);
   const RbMap all{1, 0, 1};
-  const RbMap stages[3] = {{P, 0, s0}, {P, s0, s1}, {P, s0 + s1, P - s0 - s1}};
+  RbMap stages[3] = {{P, 0, s0}, {P, s0, s1}, {P, s0 + s1, P - s0 - s1}};
   const int NW = t.threads / 64;
+  // sample size ~ sqrt(rows): the sample scan costs ~1.4 us per 1000 rows, the first filter
+  // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
+  const int srows = std::max(4096, std::min(t.filter_sample, (int)(17.0 * std::sqrt((double)rb_total * 64.0))));
+  if (phase == 2) {
+    // bounds shared by `lists` shards: their union is a sample `lists` times this shard's; when that
+    // is already worth more than the rows of the short stages, these stages only cost launches
+    const long long early = ((long long)rbmap_count(rb_total, stages[0]) + rbmap_count(rb_total, stages[1])) * 64;
+    const bool keep = t.filter_shared_stage1 < 0 ? (long long)sb->lists * srows < 2 * early : t.filter_shared_stage1 != 0;
+    if (!keep) {
+      stages[0].width = 0;
+      stages[1].width = 0;
+      stages[2] = RbMap{P, 0, P};
+    }
+  }
 
   // chunks per query tile: enough workgroups to fill the chip, but every workgroup stages its
-  // 128 KiB of tables once, so it should get >= 256 row blocks (16 per wave) where the range allows
+  // 64-128 KiB of tables once (268 MB through L2 for 4096 workgroups), so it should get >= 768 row blocks
+  // (48 per wave) where the range allows: 1.25 M rows measure 0.420 ms in 1600 workgroups, 0.436 in 4096
   auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
     const int most = std::max(1, ceil_div(target, tiles));        // launch-size cap
     const int fill = std::max(1, ceil_div(256, tiles));           // one workgroup per CU
-    int nc = std::max(fill, std::min(most, e_count / 256));
+    int nc = std::max(fill, std::min(most, e_count / 768));
     nc = std::min(nc, std::max(1, e_count / NW));                 // at least one block per wave
     per = ceil_div(e_count, nc);
     nchunks = ceil_div(e_count, per);
@@ -590,7 +646,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   ix->sv_queue.ensure((size_t)Bq * NSLOT * cap);
   ix->fb_tile.ensure((size_t)ntiles);
   ix->tau0.ensure((size_t)Bp);
-  {
+  if (phase != 2) {
     const int most = std::max(std::max(Bp, ntiles), Bq * NSLOT);
     hipLaunchKernelGGL(filter_reset, dim3(ceil_div(most, 256)), dim3(256), 0, st, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,
                        ix->sv_cnt.p, Bq * NSLOT);
@@ -599,11 +655,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 
   // the table minima of the B real queries come out of the table build; the padding queries of the
   // last 16-query quantisation group are dead and never read theirs
-  launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st, nullptr, ix->qmins.p);
-  {   // bounds from a strided sample of about filter_sample rows; resets the running lists
-    // sample size ~ sqrt(rows): the sample scan costs ~1.4 us per 1000 rows, the first filter
-    // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
-    const int srows = std::max(4096, std::min(t.filter_sample, (int)(17.0 * std::sqrt((double)rb_total * 64.0))));
+  if (phase != 2) launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st, nullptr, ix->qmins.p);
+  if (phase != 2) {   // bounds from a strided sample of about filter_sample rows; resets the running lists
     int sblocks = std::max(NW, std::min(rb_total, ceil_div(srows, 64)));
     const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
     const int se = rbmap_count(rb_total, smap);
@@ -615,11 +668,16 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                   \
       hipLaunchKernelGGL(kern, dim3(Bp / W_), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,  \
                          ix->tables.p, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p,           \
-                         ix->fin_i.p);                                                                              \
+                         ix->fin_i.p, phase == 1 ? sb->bounds_out : nullptr);                                       \
     }
     if (ix->vec == 16) { if (W == 4) BS(16, 4) else if (W == 2) BS(16, 2) else BS(16, 1) }
     else               { if (W == 4) BS(4, 4) else if (W == 2) BS(4, 2) else BS(4, 1) }
 #undef BS
+    HIP_CHECK(hipGetLastError());
+  }
+  if (phase == 1) return;     // the caller exchanges the bounds and comes back with phase 2
+  if (phase == 2) {
+    hipLaunchKernelGGL(shared_tau, dim3(ceil_div(B, 4)), dim3(256), 0, st, sb->all_bounds, sb->lists, B, keff, ix->tau0.p);
     HIP_CHECK(hipGetLastError());
   }
   const bool stats = getenv("GULON_FILTER_STATS") != nullptr;

@@ -72,28 +72,36 @@ __global__ void build_tables(const float *__restrict__ cents, const int *__restr
   // one thread per (query group of W, quantizer, centroid); a block of 256 threads = the 256
   // centroids of ONE (query group, quantizer), so the per-(query, quantizer) table minimum the
   // quantized filter needs (NaN entries ignored) is a block reduction here (mins != nullptr)
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // (launched with 256 threads: quantizer and query group are block-uniform, so the query values
+  // come through scalar loads; the centroid coordinates are fetched eight at a time)
   if (live_queries) B = min(B, *live_queries);   // device-side query count (tie replay: usually 0)
-  int nqg = (B + W - 1) / W;
-  long long total = (long long)nqg * m_pad * 256;
-  if (t >= total) return;
-  int c = (int)(t & 255);
-  int j = (int)((t >> 8) % m_pad);
-  int qg = (int)((t >> 8) / m_pad);
+  const int nqg = (B + W - 1) / W;
+  if ((long long)blockIdx.x >= (long long)nqg * m_pad) return;
+  const int c = threadIdx.x;
+  const int j = blockIdx.x % m_pad;
+  const int qg = blockIdx.x / m_pad;
+  const long long t = (long long)blockIdx.x * 256 + c;
   float acc[W];
 #pragma unroll
   for (int u = 0; u < W; u++) acc[u] = 0.f;
   if (j < m && c < k) {
-    int fr = from[j], s = sdim[j];
+    const int fr = from[j], s = sdim[j];
     const float *cc = cents + (size_t)k * fr + (size_t)c * s;
-    for (int tt = 0; tt < s; tt++) {
-      float cv = cc[tt];
+    for (int t0 = 0; t0 < s; t0 += 8) {
+      float cv[8];
 #pragma unroll
-      for (int u = 0; u < W; u++) {
-        int q = qg * W + u;
-        if (q < B) {
-          float dd = Q[(size_t)q * d + fr + tt] - cv;
-          acc[u] += dd * dd;
+      for (int e = 0; e < 8; e++) cv[e] = t0 + e < s ? cc[t0 + e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (t0 + e < s) {
+#pragma unroll
+          for (int u = 0; u < W; u++) {
+            const int q = qg * W + u;
+            if (q < B) {
+              const float dd = Q[(size_t)q * d + fr + t0 + e] - cv[e];
+              acc[u] += dd * dd;
+            }
+          }
         }
       }
     }
@@ -494,7 +502,8 @@ void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpa
 ScanTuning::ScanTuning() {
   static const char *keys[] = {"GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE", "GULON_SCAN_PRUNE_FROM", "GULON_SCAN_FILTER",
                                "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
-                               "GULON_FILTER_NADD", "GULON_FILTER_SAMPLE", "GULON_FILTER_STAGE0", "GULON_FILTER_BLOCKS"};
+                               "GULON_FILTER_NADD", "GULON_FILTER_SAMPLE", "GULON_FILTER_STAGE0", "GULON_FILTER_BLOCKS",
+                               "GULON_FILTER_SHARED_STAGE1"};
   for (const char *k : keys)
     if (const char *e = getenv(k)) set(k, atoi(e));
 }
@@ -513,6 +522,7 @@ bool ScanTuning::set(const char *key, int v) {
   else if (k == "GULON_FILTER_SAMPLE") { if (v >= 1) filter_sample = v; }
   else if (k == "GULON_FILTER_STAGE0") { if (v >= 0) filter_stage0 = v; }
   else if (k == "GULON_FILTER_BLOCKS") { if (v >= 1) filter_blocks = v; }
+  else if (k == "GULON_FILTER_SHARED_STAGE1") { if (v >= -1 && v <= 1) filter_shared_stage1 = v; }
   else return false;
   return true;
 }
@@ -621,8 +631,14 @@ void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_c
 namespace {
 
 // Enqueue table build + scan + merge.  Exactly one of (final outputs) / (partial outputs) is used.
+__global__ void fill_f32(float *__restrict__ p, long long n, float v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
-               float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
+               float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st,
+               const SharedBounds *sb = nullptr) {
   GULON_REQUIRE(from <= until, "expected: from <= until");                               // Index.scala:418
   GULON_REQUIRE(from >= 0 && until <= ix->n, "expected: from >= 0 && until <= length");  // Index.scala:419
   GULON_REQUIRE(K >= 0 && B >= 0, "k and batch size must be non-negative");
@@ -630,6 +646,16 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   GULON_UNSUPPORTED(K > GULON_MAX_K && !final_out,
                     "k_nn = %d > GULON_MAX_K = %d is only supported for unsharded queries", K, GULON_MAX_K);
   if (B == 0) return;
+  if (sb && sb->phase == 1) {
+    // first half of a query with shared bounds: ranges the filter does not take have no bounds to offer
+    const int rbt = ceil_div(until, 64) - from / 64;
+    if (!(K >= 1 && rbt > 0 && filter_eligible(ix, K, rbt))) {
+      const long long nb = (long long)B * (K + 1);
+      hipLaunchKernelGGL(fill_f32, dim3((unsigned)ceil_div(nb, 256LL)), dim3(256), 0, st, sb->bounds_out, nb, INFINITY);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   const bool peeled = K > GULON_MAX_K;            // results come 64 at a time
   const int keff = peeled ? 64 : K + 1;
   const int W = ix->w;
@@ -671,7 +697,7 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   const int Bp = ntiles * QT;
   const RbMap all{1, 0, 1};
   if (!peeled && filter_eligible(ix, K, rb_total)) {
-    run_filter_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st);
+    run_filter_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st, sb);
     return;
   }
   if (peeled) {
@@ -823,6 +849,37 @@ GULON_API int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_
     std::lock_guard<std::mutex> lock(idx->mu);
     run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, d_part_dist,
               d_part_idx, (hipStream_t)stream);
+  });
+}
+
+GULON_API int32_t gulon_index_scan_bounds_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                              int32_t from, int32_t until, float *d_bounds, void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr && d_bounds != nullptr, "null argument");
+    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is only supported for unsharded queries", k_nn,
+                      GULON_MAX_K);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const SharedBounds sb{1, d_bounds, nullptr, 0};
+    idx->pend_b = -1;
+    run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+              (hipStream_t)stream, &sb);
+    idx->pend_b = b; idx->pend_k = k_nn; idx->pend_from = from; idx->pend_until = until;
+  });
+}
+
+GULON_API int32_t gulon_index_scan_partial_bounded_dev(gulon_index *idx, const float *d_queries, int32_t b,
+                                                       int32_t k_nn, int32_t from, int32_t until,
+                                                       const float *d_all_bounds, int32_t lists, float *d_part_dist,
+                                                       int32_t *d_part_idx, void *stream) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr && d_all_bounds != nullptr && lists >= 1, "bad arguments");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    GULON_REQUIRE(idx->pend_b == b && idx->pend_k == k_nn && idx->pend_from == from && idx->pend_until == until,
+                  "scan_partial_bounded must follow scan_bounds on the same index with the same arguments");
+    idx->pend_b = -1;
+    const SharedBounds sb{2, nullptr, d_all_bounds, lists};
+    run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, d_part_dist,
+              d_part_idx, (hipStream_t)stream, &sb);
   });
 }
 

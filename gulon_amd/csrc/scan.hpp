@@ -56,6 +56,8 @@ struct gulon_index {
   std::vector<hipEvent_t> ev_pool;  // created once: hipEventCreate inside the timed region is slow
   size_t ev_next = 0;
   std::mutex mu;
+  // gulon_index_scan_bounds_dev -> gulon_index_scan_partial_bounded_dev: arguments of the pending first half
+  int pend_b = -1, pend_k = -1, pend_from = -1, pend_until = -1;
   hipEvent_t take_event() {
     if (ev_next == ev_pool.size()) {
       hipEvent_t e = nullptr;
@@ -95,6 +97,7 @@ struct ScanTuning {
   int filter_cap = 32768;    // survivor queue entries per query and stage
   int filter_nadd = 0;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels, 0: by m)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch
+  int filter_shared_stage1 = -1;    // bounds shared across shards: run the short first stage? (-1: by sample size)
   ScanTuning();
   bool set(const char *key, int v);
 };
@@ -110,8 +113,14 @@ void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long lo
                           int K, float *out_pv, int *out_pi, const int *tile_enable, int qt, hipStream_t st);
 // filter.hip: sample scan -> quantized filter stages -> exact re-evaluation of the survivors.
 bool filter_eligible(const gulon_index *ix, int K, int rb_total);
+// Bounds shared across row shards (sharded.py): phase 1 stops after the sample scan and writes the K+1
+// smallest sample distances per query ([B][K+1], ascending, +inf padded) to bounds_out; phase 2 resumes
+// with the `lists` gathered arrays ([lists][B][K+1]) -- the (K+1)-th smallest of their union bounds the
+// (K+1)-th distance of the WHOLE index, so every shard filters against the global bound.
+struct SharedBounds { int phase; float *bounds_out; const float *all_bounds; int lists; };
 void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
-                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st);
+                      float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st,
+                      const SharedBounds *sb = nullptr);
 
 #ifdef __HIPCC__
 template <int VEC> struct CodeWord;

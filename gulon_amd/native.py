@@ -81,6 +81,8 @@ SIGNATURES = {
     "gulon_index_batch_query": (_i32, [_vp, _f32p, _i32, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
     "gulon_index_batch_query_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_scan_partial_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gulon_index_scan_bounds_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "gulon_index_scan_partial_bounded_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "gulon_topk_merge_dev": (_i32, [_vp, _vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_profile": (_i32, [_vp, _i32]),
     "gulon_index_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32)]),

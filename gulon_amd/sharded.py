@@ -74,6 +74,17 @@ class HipEngine:
         N.check(N.lib().gulon_index_scan_partial_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, pv.data_ptr(),
                                                      pi.data_ptr(), self._stream()))
 
+    def scan_bounds(self, q, b, k, bd):
+        """First half of scan_partial: this shard's K+1 smallest sample distances per query -> bd [B][K+1]."""
+        N.check(N.lib().gulon_index_scan_bounds_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, bd.data_ptr(),
+                                                    self._stream()))
+
+    def scan_partial_bounded(self, q, b, k, abd, lists, pv, pi):
+        """Second half: the scan against the bound of the union of all shards' samples (abd [lists][B][K+1])."""
+        N.check(N.lib().gulon_index_scan_partial_bounded_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc,
+                                                             abd.data_ptr(), lists, pv.data_ptr(), pi.data_ptr(),
+                                                             self._stream()))
+
     def merge(self, packed, lists, b, k, oi, od, oc, of):
         """packed: [lists][2][B][K+1] int32 words (distance bits, then row ids) as gathered."""
         base = packed.data_ptr()
@@ -98,14 +109,23 @@ class HipEngine:
 class ShardedIndex:
     """One rank's view of the row-sharded flat index."""
 
-    def __init__(self, engine, n_total, rank=0, world=1, dist=None):
+    def __init__(self, engine, n_total, rank=0, world=1, dist=None, rehearse=False):
         self.engine = engine
         self.n_total, self.rank, self.world, self.dist = n_total, rank, world, dist
+        # the multi-rank pipeline (partial lists -> all-gather -> merge -> replay exchange); `rehearse`
+        # runs it with a one-rank process group as well, so that the RCCL path can be exercised and
+        # timed on a one-GPU box (bench.py: GULON_BENCH_REHEARSE=1)
+        self.collective = world > 1 or (rehearse and dist is not None)
+        # shards share their pruning bounds (one more, tiny all-gather in front of the scan) when the
+        # engine can split its scan; GULON_SHARED_BOUNDS=0 keeps every shard on its own bound
+        import os
+        self.share_bounds = (self.collective and hasattr(engine, "scan_bounds")
+                             and os.environ.get("GULON_SHARED_BOUNDS", "1") != "0")
         self.lo, self.hi = shard_bounds(n_total, world, rank)
         self._bufs = {}
         # RCCL gathers device tensors directly; a gloo group (CPU rehearsal of the multi-rank path
         # with the real HIP engine) needs the lists staged through the host
-        self.host_staged = bool(dist is not None and world > 1 and dist.get_backend() == "gloo"
+        self.host_staged = bool(dist is not None and self.collective and dist.get_backend() == "gloo"
                                 and getattr(engine, "device", None) is not None)
 
     def _buffers(self, b, k):
@@ -120,8 +140,11 @@ class ShardedIndex:
                 pk=e.alloc((2 * b, k + 1), "i32"),
                 # gathered, rank-major: [world][2][B][K+1]
                 apk=e.alloc((self.world * 2 * b, k + 1), "i32"))
+            if self.share_bounds:
+                self._bufs[key]["bd"] = e.alloc((b, k + 1), "f32")
+                self._bufs[key]["abd"] = e.alloc((self.world * b, k + 1), "f32")
             words = getattr(e, "replay_words", 0)
-            if words and self.world > 1:
+            if words and self.collective:
                 self._bufs[key]["rp"] = e.alloc((words,), "i32")
                 self._bufs[key]["arp"] = e.alloc((self.world * words,), "i32")
         return self._bufs[key]
@@ -138,11 +161,16 @@ class ShardedIndex:
     def batch_query_dev(self, q, b, k):
         """Enqueue one batch; returns the (device) output tensors idx, dist, count, flags."""
         u = self._buffers(b, k)
-        if self.world == 1:
+        if not self.collective:
             self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
         else:
             pv, pi = self.engine.views(u["pk"], b)
-            self.engine.scan_partial(q, b, k, pv, pi)
+            if self.share_bounds:
+                self.engine.scan_bounds(q, b, k, u["bd"])
+                self._all_gather(u["abd"], u["bd"])
+                self.engine.scan_partial_bounded(q, b, k, u["abd"], self.world, pv, pi)
+            else:
+                self.engine.scan_partial(q, b, k, pv, pi)
             self._all_gather(u["apk"], u["pk"])
             self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
             if "rp" in u:

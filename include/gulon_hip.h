@@ -183,6 +183,25 @@ int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, in
 int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
                                      int32_t from, int32_t until, float *d_part_dist,
                                      int32_t *d_part_idx, void *stream);
+/* The same partial scan in two halves, so that ROW SHARDS can share their pruning bounds (one tiny
+ * all-gather between the halves; sharded.py).  The reference scans every row of every partition
+ * (Index.scala:424-437); the quantized filter in front of the exact arithmetic prunes against an
+ * upper bound of the (K+1)-th distance, and a bound drawn from the samples of ALL shards is
+ * `shards` times tighter than a shard's own -- results do not change, only the work.
+ *   1. gulon_index_scan_bounds_dev: table build + sample scan of this shard; d_bounds [B][K+1] =
+ *      the K+1 smallest sample distances per query, ascending, +inf padded (all +inf for ranges
+ *      the filter does not take);
+ *   2. the caller gathers the arrays of all shards: d_all_bounds [lists][B][K+1] (this shard's
+ *      own among them, any order);
+ *   3. gulon_index_scan_partial_bounded_dev: the rest of the scan against the (K+1)-th smallest
+ *      value of the union; same arguments as step 1 on the same index (GULON_ERR_INVALID_ARGUMENT
+ *      otherwise), outputs as gulon_index_scan_partial_dev.  k_nn <= GULON_MAX_K. */
+int32_t gulon_index_scan_bounds_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                    int32_t from, int32_t until, float *d_bounds, void *stream);
+int32_t gulon_index_scan_partial_bounded_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
+                                             int32_t from, int32_t until, const float *d_all_bounds,
+                                             int32_t lists, float *d_part_dist, int32_t *d_part_idx,
+                                             void *stream);
 /* Exact TopKHeap replay of tie-flagged queries across ROW SHARDS (the unsharded
  * gulon_index_batch_query* does this internally).  After gulon_topk_merge_dev every shard holds
  * the same flags; each shard then collects, for the first GULON_REPLAY_MAX_FLAGGED flagged
