@@ -287,8 +287,8 @@ template <> struct QEntry<4> { using type = uint32_t; };
 template <int QW, int NQG, int VEC, int NADD, int MAIN>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
-    int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue,
-    int cap /* entries per sub-queue */, const int *__restrict__ fb_tile, int qt, int B) {
+    int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap /* entries per sub-queue */,
+    const int *__restrict__ fb_tile, int qt, int B) {
   constexpr int NW = FILTER_THREADS / 64;
   constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
   constexpr int DW = QW / 4;     // dwords per entry
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       for (int t = q_lo / qt; t <= (q_hi - 1) / qt; t++) any_live = any_live || fb_tile[t] == 0;
     if (!any_live) return;
   }
-  const int slot = chunk & (NSLOT - 1);   // spreads the queue-tail atomics of one query over NSLOT counters
+  // spreads the queue-tail atomics of one query over NSLOT counters
+  const int slot = (chunk * NW + wave) & (NSLOT - 1);
   {
     const int n16 = NQG * tab * QW / 16;   // 16-byte units (tab * QW is a multiple of 16)
     const uint4 *src = reinterpret_cast<const uint4 *>(qtab) + (size_t)tile * n16;
@@ -382,22 +383,28 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
         any |= left[s][x];
       }
     if (__ballot(valid && any != 0) != 0ull) {
+      // rare path.  Its queue addresses are uniform and loop-invariant, and hoisted out of the scan loop
+      // they would hold ~60 SGPRs for the whole kernel -- past the 102 that still allow two workgroups per
+      // CU.  Opaque copies keep that arithmetic in here.
+      int *cnt_l = cnt, *queue_l = queue;
+      int slot_l = slot, tile_l = tile;
+      asm volatile("" : "+s"(cnt_l), "+s"(queue_l), "+s"(slot_l), "+s"(tile_l));
 #pragma unroll
       for (int s = 0; s < NQG; s++)
 #pragma unroll
         for (int x = 0; x < 2 * DW; x++) {
           const uint32_t l = valid ? left[s][x] : 0u;
           if (__ballot(l != 0) == 0ull) continue;
-          const int q0 = (tile * NQG + s) * QW + 4 * (x >> 1) + (x & 1);
+          const int q0 = (tile_l * NQG + s) * QW + 4 * (x >> 1) + (x & 1);
           if (l & 0xFFFFu) {
-            const int sq = q0 * NSLOT + slot;
-            const int pos = atomicAdd(&cnt[sq], 1);
-            if (pos < cap) queue[(size_t)sq * cap + pos] = row;
+            const int sq = q0 * NSLOT + slot_l;
+            const int pos = atomicAdd(&cnt_l[sq], 1);
+            if (pos < cap) queue_l[(size_t)sq * cap + pos] = row;
           }
           if (l >> 16) {
-            const int sq = (q0 + 2) * NSLOT + slot;
-            const int pos = atomicAdd(&cnt[sq], 1);
-            if (pos < cap) queue[(size_t)sq * cap + pos] = row;
+            const int sq = (q0 + 2) * NSLOT + slot_l;
+            const int pos = atomicAdd(&cnt_l[sq], 1);
+            if (pos < cap) queue_l[(size_t)sq * cap + pos] = row;
           }
         }
     }
@@ -539,6 +546,21 @@ struct FilterLane {
 };
 FilterLane &filter_lane() { static FilterLane l; return l; }
 
+int device_cus() {   // compute units of the current device
+  static std::map<int, int> cus;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  auto it = cus.find(dev);
+  if (it == cus.end()) {
+    int n = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    it = cus.emplace(dev, std::max(1, n)).first;
+  }
+  return it->second;
+}
+
 // queries per quantized table entry: as many as LDS holds for one group (16 up to m_pad = 36,
 // 8 up to 72, 4 up to 144) ...
 int filter_qw(const gulon_index *ix) {
@@ -621,11 +643,16 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 
   // chunks per query tile: enough workgroups to fill the chip, but every workgroup stages its
   // 64-128 KiB of tables once (268 MB through L2 for 4096 workgroups), so it should get >= 768 row blocks
-  // (48 per wave) where the range allows: 1.25 M rows measure 0.420 ms in 1600 workgroups, 0.436 in 4096
+  // (48 per wave) where the range allows; the launch is a whole number of rounds of what the chip holds
+  // at once (CUs x resident workgroups) where that is possible
+  const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw;
+  const int resident = std::max(1, std::min(2048 / FILTER_THREADS, (int)(160 * 1024 / filter_lds)));
+  const int slots = device_cus() * resident;
   auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
     const int most = std::max(1, ceil_div(target, tiles));        // launch-size cap
-    const int fill = std::max(1, ceil_div(256, tiles));           // one workgroup per CU
+    const int fill = std::max(1, ceil_div(slots, tiles));         // every slot of the chip taken once
     int nc = std::max(fill, std::min(most, e_count / 768));
+    if (nc > fill) nc -= nc % fill;                               // whole rounds
     nc = std::min(nc, std::max(1, e_count / NW));                 // at least one block per wave
     per = ceil_div(e_count, nc);
     nchunks = ceil_div(e_count, per);
