@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GULON_BENCH_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GULON_BENCH_INFLIGHT", "0")),
                     help="query batches in flight (each on its own stream with its own scratch)")
     args = ap.parse_args()
 
@@ -111,11 +111,17 @@ def main():
     nloc = hi - lo
     coder = pq.coder_factory(nloc)
     # one engine (= device index + scratch) and one stream per batch in flight
-    nfl = max(1, args.inflight)
+    # batches in flight: 2 on one GPU (the second one fills the gaps of the first one's short kernels); 3 when
+    # the shards exchange bounds, lists and replay candidates, so that a batch waiting for its all-gathers
+    # never leaves the GPU idle (1.25 M-row shard, one-rank RCCL rehearsal: 0.602 / 0.566 / 0.561 ms for 2 / 3 / 4)
+    collective = world > 1 or rehearse
+    nfl = args.inflight if args.inflight > 0 else (3 if collective else 2)
     engines = [HipEngine(pq, shard, lo, dev) for _ in range(nfl)]
     shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse) for e in engines]
-    if "GULON_BENCH_STREAM_PRIORITY" in os.environ:
-        streams = [torch.cuda.Stream(priority=int(os.environ["GULON_BENCH_STREAM_PRIORITY"])) for _ in range(nfl)]
+    if collective:
+        # side streams only: work on the legacy default stream serialises with the collectives' stream
+        # (rehearsal, two batches in flight: 0.716 ms per step with the default stream among them, 0.615 without)
+        streams = [torch.cuda.Stream() for _ in range(nfl)]
     else:
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
     engine, sharded, index = engines[0], shardeds[0], engines[0].index

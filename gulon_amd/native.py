@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgulon_hip.so")
+# GULON_HIP_LIB: another build of the same library (A/B measurements of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("GULON_HIP_LIB") or os.path.join(_HERE, "lib", "libgulon_hip.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
