@@ -630,10 +630,11 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   // stage's slow path ~ rows / sample -- 54 K rows at 10 M, 19 K at 1.25 M; filter_sample caps it
   const int srows = std::max(4096, std::min(t.filter_sample, (int)(17.0 * std::sqrt((double)rb_total * 64.0))));
   if (phase == 2) {
-    // bounds shared by `lists` shards: their union is a sample `lists` times this shard's; when that
-    // is already worth more than the rows of the short stages, these stages only cost launches
+    // bounds shared by `lists` shards: their union is a sample `lists` times this shard's; once that
+    // is about half the rows of the short stages, these stages cost more launches than they save survivors
+    // (one rank of 2 / 4 / 8 on the bench index: 1.950 / 1.136 / 0.526 ms with them, 1.944 / 1.074 / 0.496 without)
     const long long early = ((long long)rbmap_count(rb_total, stages[0]) + rbmap_count(rb_total, stages[1])) * 64;
-    const bool keep = t.filter_shared_stage1 < 0 ? (long long)sb->lists * srows < 2 * early : t.filter_shared_stage1 != 0;
+    const bool keep = t.filter_shared_stage1 < 0 ? 2LL * sb->lists * srows < early : t.filter_shared_stage1 != 0;
     if (!keep) {
       stages[0].width = 0;
       stages[1].width = 0;
