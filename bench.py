@@ -255,6 +255,23 @@ def main():
                     "sample": f"first {n_q} of the {B} queries over all {n} rows, single thread, "
                               f"4096-row blocks (Index.scala:424); C restatement of Gulon's JVM algorithm"}
                 result["parity_vs_oracle"] = {"queries": n_q, "distances_bit_exact": same_d, "ids_equal": same_i}
+                # the same restatement with the queries striped over the host cores -- one index.query per
+                # task, as Tests.recallOf runs them (Tests.scala:22-29, parTraverse); a second, bounded sample
+                cores = min(len(os.sched_getaffinity(0)), 16)
+                if cores > 1 and args.cpu_seconds > 0:
+                    from concurrent.futures import ThreadPoolExecutor
+                    per_thread = max(1, min(int(0.6 * args.cpu_seconds * (n_q / t_cpu)), B // cores))
+                    sl = [Qh[i * per_thread:(i + 1) * per_thread] for i in range(cores)]
+                    t = time.perf_counter()
+                    with ThreadPoolExecutor(cores) as ex:       # ctypes releases the GIL inside the C scan
+                        outs = list(ex.map(lambda q: oracle.pq_batch_query(codes_h, d, k, cents, q, K), sl))
+                    dt = time.perf_counter() - t
+                    par_d = np.concatenate([o[1] for o in outs])
+                    result["cpu_baseline_all_cores"] = {
+                        "value": cores * per_thread / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+                        "sample": f"first {cores * per_thread} queries, {per_thread} per thread, all {n} rows",
+                        "distances_bit_exact": bool(np.array_equal(par_d.view(np.uint32),
+                                                                   res_dist[:cores * per_thread].view(np.uint32)))}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:

@@ -659,7 +659,12 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     nchunks = ceil_div(e_count, per);
   };
 
-  const int cfb = std::max(1, ceil_div(256, ntiles));   // fallback: one workgroup per CU when everything is redone
+  // fallback launch: W-query tiles with ONE sub-table (<= 64 KiB of LDS, like a filter workgroup).  The index's
+  // preferred two-sub-table workgroup needs both LDS halves of a CU at once, which another batch's filter
+  // kernel never leaves free: the (normally empty) launch then waited for that whole kernel -- up to 3 ms
+  // of its batch's critical path (rocprofv3: 1.31 ms on average for a launch that takes 4.7 us)
+  const int fb_tiles = ntiles * ix->nsub;
+  const int cfb = std::max(1, ceil_div(256, fb_tiles));   // one workgroup per CU when everything is redone
   const int pfb = ceil_div(rb_total, cfb);
   const int cfb_n = ceil_div(rb_total, pfb);
   ix->tables.ensure((size_t)Bp * ix->m_pad * 256);
@@ -772,7 +777,19 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   }
 
   // fallback (device-side decision): flagged query tiles are rescanned exactly over all rows
-  launch_scan(ix, ntiles, cfb_n, rb_begin, rb_total, pfb, all, from, until, keff, st, nullptr, nullptr, ix->fb_tile.p);
+  {
+    if (!ix->fb_hint_h) {
+      HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ix->fb_hint_h), sizeof(int), hipHostMallocMapped));
+      *ix->fb_hint_h = 0;
+      HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ix->fb_hint_d), ix->fb_hint_h, 0));
+    }
+    // a hint, read without synchronisation: did a recent fallback launch of this index find work?
+    volatile int *hint = ix->fb_hint_h;
+    const bool wide = *hint != 0;
+    if (wide) *hint = 0;                  // decays unless the wide launch finds work again
+    launch_scan(ix, fb_tiles, cfb_n, rb_begin, rb_total, pfb, all, from, until, keff, st, nullptr, nullptr,
+                ix->fb_tile.p, true, wide ? fb_tiles : 8, ix->fb_hint_d);
+  }
   launch_merge_enabled(ix->part_v.p, ix->part_i.p, cfb_n, (long long)keff, (long long)cfb_n * keff, B, K, ix->fin_v.p,
                        ix->fin_i.p, ix->fb_tile.p, QT, st);
 

@@ -144,14 +144,13 @@ template <> struct TabVec<2> { using type = float2; };
 template <> struct TabVec<1> { using type = float; };
 
 template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
-__global__ __launch_bounds__(THREADS) void scan_kernel(
+__device__ __forceinline__ void scan_body(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables,
     int row_from, int row_until, int row_base, int rb_begin, int e_count, int e_per_chunk, RbMap mp, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
     int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi,
-    const int *__restrict__ tile_enable, unsigned long long *__restrict__ dbg) {
+    const int tile /* query tile of this pass */, unsigned long long *__restrict__ dbg) {
   constexpr int QT = W * NSUB;
-  if (tile_enable && tile_enable[blockIdx.x] == 0) return;   // filter fallback: only flagged query tiles
   // optional timeline (GULON_SCAN_TIMELINE=1): 4 stamps per workgroup, 100 MHz wall clock
   if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = wall_clock64();
   constexpr int NW = THREADS / 64;
@@ -163,7 +162,6 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;   // query tile (fastest: tiles of one chunk run together)
   const int chunk = blockIdx.y;
   const int tab_entries = m_pad * 256;  // entries (of W floats) per sub-table
 
@@ -348,6 +346,43 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(
   }
   if (dbg && threadIdx.x == 0) dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = wall_clock64();
 }
+
+#define GULON_SCAN_PARAMS                                                                                          \
+  const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables, int row_from,           \
+      int row_until, int row_base, int rb_begin, int e_count, int e_per_chunk, RbMap mp, int nchunks, int keff,     \
+      float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,              \
+      int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi
+#define GULON_SCAN_ARGS                                                                                            \
+  codes, ng, m_pad, tables, row_from, row_until, row_base, rb_begin, e_count, e_per_chunk, mp, nchunks, keff,      \
+      part_v, part_i, gtau, tau_off4, prune_from, lbv, lbi
+
+// workgroup (x, y) = query tile x (fastest: the tiles of one chunk run together) x chunk y of the row blocks
+template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
+__global__ __launch_bounds__(THREADS) void scan_kernel(GULON_SCAN_PARAMS, unsigned long long *__restrict__ dbg) {
+  scan_body<W, NSUB, VEC, THREADS, PRUNE>(GULON_SCAN_ARGS, (int)blockIdx.x, dbg);
+}
+
+// The filter's fallback launch: only the query tiles flagged in tile_enable (one flag per tile_div tiles) are
+// scanned, normally none.  It sits on the critical path of its batch while ANOTHER batch's filter kernel
+// fills the chip, and a workgroup is dispatched only where a leaving filter workgroup makes room: 64 KiB of
+// LDS and, per SIMD, 4 x 56 + 64 = 288 registers.  Four waves of the regular one-sub-table instantiation
+// (84 VGPRs) need 352 and waited for a completely empty CU -- for the other batch's whole 3 ms kernel --, so
+// this twin is compiled for 7 waves per SIMD (<= 72 VGPRs); and since even then every workgroup waits for
+// its turn (256 empty workgroups: 0.9 ms on average), the launch is `gridDim.x` workgroups wide, each
+// looping over the tiles x, x + gridDim.x, ...: narrow while nothing falls back, wide once something did
+// (*hint, host-mapped, read by the host when it sizes the next launch).
+template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(7))) void scan_kernel_lean(
+    GULON_SCAN_PARAMS, const int *__restrict__ tile_enable, int tile_div, int ntiles, int *__restrict__ hint) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tile_enable[tile / tile_div] == 0) continue;
+    if (hint && threadIdx.x == 0 && blockIdx.y == 0) *hint = 1;
+    scan_body<W, NSUB, VEC, THREADS, PRUNE>(GULON_SCAN_ARGS, tile, nullptr);
+    __syncthreads();   // every wave is done with this tile's tables and thresholds in LDS
+  }
+}
+#undef GULON_SCAN_PARAMS
+#undef GULON_SCAN_ARGS
 
 // ---------------------------------------------------------------------------
 // merge `lists` sorted partial lists per query; one wave per query.
@@ -548,7 +583,7 @@ constexpr size_t LDS_BUDGET = 144 * 1024;
 template <int W, int NSUB, int VEC, int SCAN_THREADS, bool PRUNE>
 void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                    int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
-                   const int *tile_enable) {
+                   const int *tile_enable, int tile_div, int grid_x, int *hint) {
   size_t lds_bytes = (size_t)NSUB * ix->m_pad * 256 * W * sizeof(float);
   size_t merge_bytes = (size_t)W * NSUB * (SCAN_THREADS / 64) * 64 * 8;
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
@@ -561,13 +596,28 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
     ix->dbg.ensure((size_t)ntiles * nchunks * 4);
     dbg = ix->dbg.p;
   }
+  if (tile_enable) {   // the filter's fallback (launch_scan with one_sub): grid_x workgroups loop over the tiles
+    if constexpr (NSUB == 1) {
+      auto kern = scan_kernel_lean<W, NSUB, VEC, SCAN_THREADS, PRUNE>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+      hipLaunchKernelGGL(kern, dim3(std::max(1, std::min(grid_x, ntiles)), nchunks), dim3(SCAN_THREADS), lds_bytes, st,
+                         ix->codes.p, ix->ng, ix->m_pad, reinterpret_cast<const float4 *>(ix->tables.p), from, until,
+                         ix->row_base, rb_begin, e_count, e_per_chunk, mp, nchunks, keff, ix->part_v.p, ix->part_i.p,
+                         ix->gtau.p, tau_off4, prune_from, lbv, lbi, tile_enable, tile_div, ntiles, hint);
+      HIP_CHECK(hipGetLastError());
+      return;
+    } else {
+      GULON_REQUIRE(false, "internal: tile-enabled scans use one sub-table");
+    }
+  }
   auto kern = scan_kernel<W, NSUB, VEC, SCAN_THREADS, PRUNE>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, e_count,
                      e_per_chunk, mp, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
-                     lbi, tile_enable, dbg);
+                     lbi, dbg);
   HIP_CHECK(hipGetLastError());
   if (dbg) {   // debugging aid: synchronous dump of the per-workgroup timeline
     HIP_CHECK(hipStreamSynchronize(st));
@@ -594,14 +644,14 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
 template <int W, int NSUB, int VEC>
 void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                    int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
-                   const int *tile_enable) {
+                   const int *tile_enable, int tile_div, int grid_x, int *hint) {
   constexpr int TH = 1024;
   if (tuning().prune)
     launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff,
-                                          st, lbv, lbi, tile_enable);
+                                          st, lbv, lbi, tile_enable, tile_div, grid_x, hint);
   else
     launch_scan_p<W, NSUB, VEC, TH, false>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff,
-                                           st, lbv, lbi, tile_enable);
+                                           st, lbv, lbi, tile_enable, tile_div, grid_x, hint);
 }
 
 }  // namespace
@@ -609,15 +659,21 @@ void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
 namespace gulon {
 void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                  int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
-                 const int *tile_enable) {
+                 const int *tile_enable, bool one_sub, int grid_x, int *hint) {
+  // tile_enable (the filter's fallback) comes with one_sub: W-query tiles (one sub-table, <= 64 KiB of LDS)
+  // whatever the index prefers; ntiles counts THOSE tiles, tile_enable keeps one flag per ix->nsub of them,
+  // and grid_x workgroups per chunk loop over them
+  GULON_REQUIRE((tile_enable != nullptr) == one_sub, "internal: tile_enable <=> one_sub");
+  const int nsub = one_sub ? 1 : ix->nsub;
+  const int tile_div = one_sub ? ix->nsub : 1;
 #define GO(WW, NS, V)                                                                                          \
   launch_scan_t<WW, NS, V>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff, st, lbv, lbi, \
-                           tile_enable)
+                           tile_enable, tile_div, grid_x, hint)
   if (ix->w == 4) {
     if (ix->vec == 16) {
-      if (ix->nsub == 4) GO(4, 4, 16); else if (ix->nsub == 2) GO(4, 2, 16); else GO(4, 1, 16);
+      if (nsub == 4) GO(4, 4, 16); else if (nsub == 2) GO(4, 2, 16); else GO(4, 1, 16);
     } else {
-      if (ix->nsub == 4) GO(4, 4, 4); else if (ix->nsub == 2) GO(4, 2, 4); else GO(4, 1, 4);
+      if (nsub == 4) GO(4, 4, 4); else if (nsub == 2) GO(4, 2, 4); else GO(4, 1, 4);
     }
   } else if (ix->w == 2) {
     if (ix->vec == 16) GO(2, 1, 16); else GO(2, 1, 4);

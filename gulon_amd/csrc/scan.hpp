@@ -58,6 +58,8 @@ struct gulon_index {
   std::mutex mu;
   // gulon_index_scan_bounds_dev -> gulon_index_scan_partial_bounded_dev: arguments of the pending first half
   int pend_b = -1, pend_k = -1, pend_from = -1, pend_until = -1;
+  // host-mapped word the filter's fallback launch sets when it had anything to do: sizes the next one
+  int *fb_hint_h = nullptr, *fb_hint_d = nullptr;
   hipEvent_t take_event() {
     if (ev_next == ev_pool.size()) {
       hipEvent_t e = nullptr;
@@ -68,6 +70,7 @@ struct gulon_index {
   }
   ~gulon_index() {
     for (auto &e : ev_pool) (void)hipEventDestroy(e);
+    if (fb_hint_h) (void)hipHostFree(fb_hint_h);
   }
 };
 
@@ -107,7 +110,7 @@ ScanTuning &tuning();
 // ([query][nchunks][keff]); tile_enable (device, per query tile) skips disabled tiles.
 void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                  int from, int until, int keff, hipStream_t st, const float *lbv = nullptr, const int *lbi = nullptr,
-                 const int *tile_enable = nullptr);
+                 const int *tile_enable = nullptr, bool one_sub = false, int grid_x = 0, int *hint = nullptr);
 // merge_lists<false> restricted to the queries of enabled tiles (fallback of the filter)
 void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long long stride_l, long long stride_q, int B,
                           int K, float *out_pv, int *out_pi, const int *tile_enable, int qt, hipStream_t st);
