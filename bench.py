@@ -111,11 +111,12 @@ def main():
     nloc = hi - lo
     coder = pq.coder_factory(nloc)
     # one engine (= device index + scratch) and one stream per batch in flight
-    # batches in flight: 2 on one GPU (the second one fills the gaps of the first one's short kernels); 3 when
-    # the shards exchange bounds, lists and replay candidates, so that a batch waiting for its all-gathers
-    # never leaves the GPU idle (1.25 M-row shard, one-rank RCCL rehearsal: 0.602 / 0.566 / 0.561 ms for 2 / 3 / 4)
+    # batches in flight: 2 on one GPU (the second one fills the gaps of the first one's short kernels); 4 when
+    # the shards exchange bounds, lists and replay candidates -- a batch waiting for its all-gathers (whose
+    # kernels queue for compute units behind a running filter kernel like every other launch) must not leave
+    # the GPU idle (1.25 M-row shard, one-rank RCCL rehearsal: 0.602 / 0.566 / 0.561 ms for 2 / 3 / 4)
     collective = world > 1 or rehearse
-    nfl = args.inflight if args.inflight > 0 else (3 if collective else 2)
+    nfl = args.inflight if args.inflight > 0 else (4 if collective else 2)
     engines = [HipEngine(pq, shard, lo, dev) for _ in range(nfl)]
     shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse) for e in engines]
     if collective:
