@@ -595,7 +595,7 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 
 bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
   const ScanTuning &t = tuning();
-  return t.filter && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 256 * 4 <= FILTER_LDS_BUDGET &&
+  return t.filter && !ix->wide && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 256 * 4 <= FILTER_LDS_BUDGET &&
          rb_total >= t.filter_min_rb && rb_total >= t.filter_period;
 }
 

@@ -658,6 +658,7 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
     GULON_REQUIRE(out != nullptr, "out is null");
     *out = nullptr;
     GULON_REQUIRE(g >= 1 && group_centroids != nullptr && (g == 1 || offsets != nullptr), "bad grouping");
+    GULON_UNSUPPORTED(k > 256, "k = %d > 256 (code widths 10/12/16) is not supported by the grouped index", k);
     // GroupedIndex asserts centroids.length == offsets.length + 1 (Index.scala:240-241); offsets ascend
     std::vector<int> bounds((size_t)g + 1);
     bounds[0] = 0;

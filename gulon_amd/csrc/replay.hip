@@ -372,9 +372,10 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
 void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
                     int C, int *pack, hipStream_t st) {
   const Pack pk{pack, F, C};
-  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, B, pk);
+  // (wide codes, k > 256: no replay -- an empty pack, the tie flags stay as the merge set them)
+  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, ix->wide ? 0 : B, pk);
   HIP_CHECK(hipGetLastError());
-  if (until <= from) return;
+  if (until <= from || ix->wide) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
   const int gy = std::min(F, 16);   // y extent of the scan grids
   // level geometry (in 64-row blocks)
@@ -449,7 +450,7 @@ void replay_apply(const int *packs, int lists, long long stride_words, int F, in
 
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
                     int *d_oc, int *d_of, hipStream_t st) {
-  if (B <= 0 || K <= 0 || until <= from) return;
+  if (B <= 0 || K <= 0 || until <= from || ix->wide) return;
   const int F = std::min(B, RP_MAXF), C = RP_POOL;
   ix->rp_pack.ensure(replay_pack_words(F, C));
   unsigned long long *dbgp = nullptr;

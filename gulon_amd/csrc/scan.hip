@@ -750,6 +750,10 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   int rb_per_chunk = ceil_div(rb_total, nchunks);
   nchunks = ceil_div(rb_total, rb_per_chunk);
 
+  if (ix->wide) {
+    run_wide_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st);
+    return;
+  }
   const int Bp = ntiles * QT;
   const RbMap all{1, 0, 1};
   if (!peeled && filter_eligible(ix, K, rb_total)) {
@@ -822,9 +826,33 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
     GULON_REQUIRE(cents != nullptr && (codes != nullptr || n == 0), "null input");
     int width = -1;
     GULON_REQUIRE(gulon_coder_width(k, &width) == GULON_OK && width >= 0, "too many clusters: %d", k);  // PQ.scala:12-15
-    GULON_UNSUPPORTED(k > 256, "k = %d > 256 (code widths 10/12/16) is not supported by the scan yet", k);
     std::unique_ptr<gulon_index> ix(new gulon_index());
     ix->n = n; ix->d = d; ix->m = m; ix->k = k; ix->row_base = row_base;
+    if (k > 256) {
+      // Coder.BytePlus widths 10/12/16 (Coder.scala:99-127): 16-bit codes, tables in HBM (wide.hip)
+      ix->wide = true;
+      std::vector<int> from, until, sdim(m);
+      subvectors(d, m, from, until);
+      for (int j = 0; j < m; j++) sdim[j] = until[j] - from[j];
+      ix->from.upload(from.data(), m);
+      ix->sdim.upload(sdim.data(), m);
+      ix->cents.upload(cents, (size_t)k * d);
+      int bytes_per_code = 0;
+      gulon_coder_bytes(width, n, &bytes_per_code);
+      DevBuf<uint16_t> wide16(std::max<size_t>((size_t)m * n, 1));
+      if (n > 0) {
+        DevBuf<uint8_t> packed;
+        packed.upload(codes, (size_t)m * bytes_per_code);
+        const long long tot = (long long)m * n;
+        hipLaunchKernelGGL(unpack_codes, dim3(ceil_div(tot, 256)), dim3(256), 0, 0, packed.p, width, n, bytes_per_code, m,
+                           wide16.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+      }
+      wide_store_codes(ix.get(), wide16.p);
+      *out = ix.release();
+      return;
+    }
     ix->vec = (m % 16 == 0) ? 16 : 4;
     ix->ng = ceil_div(m, ix->vec);
     ix->m_pad = ix->ng * ix->vec;
@@ -1050,7 +1078,6 @@ GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, 
                                       int32_t b, float *t_out) {
   return guarded([&] {
     GULON_REQUIRE(d >= 1 && m >= 1 && m <= d && k >= 1 && b >= 0, "bad shape");
-    GULON_UNSUPPORTED(k > 256, "k = %d > 256 is not supported yet", k);
     if (b == 0) return;
     std::vector<int> from, until, sdim(m);
     subvectors(d, m, from, until);
@@ -1058,6 +1085,12 @@ GULON_API int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, 
     DevBuf<int> dfrom, dsd; DevBuf<float> dc, dq, dt((size_t)b * m * k);
     dfrom.upload(from.data(), m); dsd.upload(sdim.data(), m);
     dc.upload(cents, (size_t)k * d); dq.upload(queries, (size_t)b * d);
+    if (k > 256) {
+      launch_build_tables_wide(dc.p, dfrom.p, dsd.p, d, m, k, dq.p, 0, b, dt.p, nullptr);
+      dt.download(t_out, (size_t)b * m * k);
+      HIP_CHECK(hipDeviceSynchronize());
+      return;
+    }
     long long total = (long long)((b + 3) / 4) * m * 256;
     hipLaunchKernelGGL((build_tables<false, 4>), dim3(ceil_div(total, 256)), dim3(256), 0, 0, dc.p, dfrom.p, dsd.p, d, m, k,
                        m, dq.p, b, dt.p, (const int *)nullptr, (float *)nullptr);

@@ -27,6 +27,8 @@ struct gulon_index {
   int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
   int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
   DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
+  bool wide = false;       // k > 256: 16-bit codes, tables in HBM (wide.hip)
+  DevBuf<uint16_t> wcodes; // wide: [n/64][m][64]
   DevBuf<float> cents;     // k*d
   DevBuf<int> from, sdim;  // m
   // scratch, grown on demand under `mu`
@@ -105,6 +107,13 @@ struct ScanTuning {
   bool set(const char *key, int v);
 };
 ScanTuning &tuning();
+
+// wide.hip: indexes with more than 256 centroids per quantizer (code widths 10/12/16)
+void wide_store_codes(gulon_index *ix, const uint16_t *wide16 /* device, [m][n] */);
+void launch_build_tables_wide(const float *cents, const int *from, const int *sdim, int d, int m, int k, const float *dQ,
+                              int q0, int nq, float *tables /*[nq][m][k]*/, hipStream_t st);
+void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
+                    float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st);
 
 // scan.hip: exact scan of the selected row blocks of [from, until) into ix->part_v/part_i
 // ([query][nchunks][keff]); tile_enable (device, per query tile) skips disabled tiles.

@@ -1,0 +1,183 @@
+// PQ indexes with more than 256 centroids per quantizer: the 10-, 12- and 16-bit codes of
+// Coder.BytePlus (Coder.scala:99-127,142-168; ProductQuantizer.coderFactory,
+// ProductQuantizer.scala:11-16, picks them for 256 < numClusters <= 65 536).
+//
+// The byte-coded kernels keep a query's m x 256 table (or its 8-bit image) in LDS; with k entries per
+// quantizer a table is m * k * 4 B -- 64 KiB at m = 16, k = 1024, 4 MiB at k = 65 536.  This path keeps
+// the reference's arithmetic (Index.scala:352-383 table, Index.scala:424-437 j-ordered unfused fp32
+// sum, (distance, row) order of the lists) and trades speed for generality:
+//
+//   codes    uint16 per (row, quantizer), row-blocked [n / 64][m][64]: a wave reads one quantizer's
+//            64 codes with one coalesced 128-byte load;
+//   tables   fp32 [query][m][k] in HBM (built per sub-batch of queries, <= 1 GiB at a time);
+//   scan     one workgroup (8 waves) per (query, chunk of row blocks): the query's table in LDS when
+//            m * k * 4 B fits 128 KiB, else gathered from L2/HBM; lane = row; every wave keeps its own
+//            sorted top-(K+1) list in registers (WaveList), written out as one partial list per wave;
+//   merge    the common merge_lists of scan.hip (ties flagged; the exact TopKHeap replay of tied
+//            queries is not built for wide codes: their flags come back without GULON_FLAG_EXACT_REPLAY).
+#include "scan.hpp"
+
+namespace gulon {
+
+namespace {
+
+constexpr int WIDE_THREADS = 512;
+constexpr int WIDE_NW = WIDE_THREADS / 64;
+constexpr size_t WIDE_LDS_TABLE = 128 * 1024;
+constexpr size_t WIDE_TABLE_BYTES = 1ull << 30;   // tables of one sub-batch of queries
+
+__global__ void relayout_wide(const uint16_t *__restrict__ src /*[m][n]*/, int n, int m,
+                              uint16_t *__restrict__ dst /*[n/64][m][64]*/, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lane = (int)(t & 63);
+  const long long bj = t >> 6;
+  const int j = (int)(bj % m);
+  const long long rb = bj / m;
+  const long long row = rb * 64 + lane;
+  dst[t] = row < n ? src[(size_t)j * n + row] : (uint16_t)0;
+}
+
+// Index.prepareQuery (Index.scala:352-383) for any k: T[q][j][c] = sum_t (q[from_j + t] - c_j[c][t])^2,
+// t ascending, unfused.  Workgroup = 256 centroids of one (query, quantizer): the query values are
+// block-uniform scalar loads.
+__global__ __launch_bounds__(256) void build_tables_wide(const float *__restrict__ cents, const int *__restrict__ from,
+                                                         const int *__restrict__ sdim, int d, int m, int k,
+                                                         const float *__restrict__ Q, int q0,
+                                                         float *__restrict__ T /*[queries of the sub-batch][m][k]*/) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.y;
+  const int ql = blockIdx.z;
+  if (c >= k) return;
+  const int fr = from[j], s = sdim[j];
+  const float *cc = cents + (size_t)k * fr + (size_t)c * s;
+  const float *qq = Q + (size_t)(q0 + ql) * d + fr;
+  float acc = 0.f;
+  for (int t = 0; t < s; t++) {
+    const float dd = qq[t] - cc[t];
+    acc += dd * dd;
+  }
+  T[((size_t)ql * m + j) * k + c] = acc;
+}
+
+template <bool LDS_T>
+__global__ __launch_bounds__(WIDE_THREADS) void scan_wide(const uint16_t *__restrict__ codes, int m, int k,
+                                                          const float *__restrict__ tables, int row_from,
+                                                          int row_until, int row_base, int rb_begin, int rb_total,
+                                                          int rb_per_chunk, int nchunks, int keff,
+                                                          float *__restrict__ part_v, int *__restrict__ part_i) {
+  extern __shared__ float wide_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = blockIdx.x, chunk = blockIdx.y;
+  const float *T = tables + (size_t)q * m * k;
+  if (LDS_T) {
+    for (int e = tid; e < m * k; e += WIDE_THREADS) wide_lds[e] = T[e];
+    __syncthreads();
+  }
+  const float *tab = LDS_T ? wide_lds : T;
+  WaveList wl;
+  wl.init();
+  int cnt = 0;
+  const int e0 = chunk * rb_per_chunk, e1 = min(rb_total, e0 + rb_per_chunk);
+  for (int e = e0 + wave; e < e1; e += WIDE_NW) {
+    const int rb = rb_begin + e;
+    const uint16_t *p = codes + (size_t)rb * m * 64 + lane;
+    float acc = 0.f;                                 // the reference's order: j ascending, unfused fp32
+    int j = 0;
+    for (; j + 4 <= m; j += 4) {
+      const int c0 = p[(size_t)(j + 0) * 64], c1 = p[(size_t)(j + 1) * 64];
+      const int c2 = p[(size_t)(j + 2) * 64], c3 = p[(size_t)(j + 3) * 64];
+      const float t0 = tab[(size_t)(j + 0) * k + c0], t1 = tab[(size_t)(j + 1) * k + c1];
+      const float t2 = tab[(size_t)(j + 2) * k + c2], t3 = tab[(size_t)(j + 3) * k + c3];
+      acc += t0; acc += t1; acc += t2; acc += t3;
+    }
+    for (; j < m; j++) acc += tab[(size_t)j * k + p[(size_t)j * 64]];
+    const int row = rb * 64 + lane;
+    const bool valid = row >= row_from && row < row_until;
+    unsigned long long mk = __ballot(valid && acc <= wl.tau);
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float cv = readlane_f(acc, l);
+      const int cr = rb * 64 + l + row_base;
+      if (cnt < keff || wl.accepts(cv, cr)) {
+        wl.insert(cv, cr, keff, lane);
+        if (cnt < keff) cnt++;
+      }
+    }
+  }
+  if (lane < keff) {
+    const size_t o = (((size_t)q * nchunks + chunk) * WIDE_NW + wave) * keff + lane;
+    part_v[o] = wl.v;
+    part_i[o] = wl.i;
+  }
+}
+
+}  // namespace
+
+// codes of a wide index: `wide16` = [m][n] uint16 on the device -> row-blocked layout
+void wide_store_codes(gulon_index *ix, const uint16_t *wide16) {
+  const size_t nblk = (size_t)ceil_div(ix->n, 64);
+  ix->wcodes.alloc(std::max<size_t>(nblk * ix->m * 64, 64));
+  if (ix->n <= 0) return;
+  const long long total = (long long)nblk * ix->m * 64;
+  hipLaunchKernelGGL(relayout_wide, dim3((unsigned)ceil_div(total, 256LL)), dim3(256), 0, 0, wide16, ix->n, ix->m,
+                     ix->wcodes.p, total);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipDeviceSynchronize());
+}
+
+void launch_build_tables_wide(const float *cents, const int *from, const int *sdim, int d, int m, int k, const float *dQ,
+                              int q0, int nq, float *tables, hipStream_t st) {
+  for (int z0 = 0; z0 < nq; z0 += 32768) {   // grid.z <= 65535
+    const int nz = std::min(32768, nq - z0);
+    hipLaunchKernelGGL(build_tables_wide, dim3(ceil_div(k, 256), m, nz), dim3(256), 0, st, cents, from, sdim, d, m, k, dQ,
+                       q0 + z0, tables + (size_t)z0 * m * k);
+    HIP_CHECK(hipGetLastError());
+  }
+}
+
+// Table build + scan + merge of one batch over rows [from, until) of a wide index (run_query's contract).
+void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
+                    float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st) {
+  GULON_UNSUPPORTED(K > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is not supported for k = %d centroids", K, GULON_MAX_K,
+                    ix->k);
+  const int keff = K + 1, m = ix->m, k = ix->k;
+  const int rb_begin = from / 64, rb_total = ceil_div(until, 64) - rb_begin;
+  const size_t table_bytes = (size_t)m * k * sizeof(float);
+  const bool lds_t = table_bytes <= WIDE_LDS_TABLE;
+  const int qb = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, WIDE_TABLE_BYTES / table_bytes));
+  // chunks: ~2048 workgroups per launch, at least 2 row blocks per wave
+  int nchunks = std::max(1, std::min(ceil_div(2048, std::min(qb, B)), rb_total / (2 * WIDE_NW)));
+  const int rb_per_chunk = ceil_div(rb_total, nchunks);
+  nchunks = ceil_div(rb_total, rb_per_chunk);
+  const int lists = nchunks * WIDE_NW;
+  ix->tables.ensure((size_t)qb * m * k);
+  ix->part_v.ensure((size_t)qb * lists * keff);
+  ix->part_i.ensure((size_t)qb * lists * keff);
+  int *flags = d_of;
+  for (int q0 = 0; q0 < B; q0 += qb) {
+    const int nq = std::min(qb, B - q0);
+    launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, m, k, dQ, q0, nq, ix->tables.p, st);
+    if (lds_t) {
+      auto kern = scan_wide<true>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)table_bytes));
+      hipLaunchKernelGGL(kern, dim3(nq, nchunks), dim3(WIDE_THREADS), table_bytes, st, ix->wcodes.p, m, k, ix->tables.p,
+                         from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff, ix->part_v.p,
+                         ix->part_i.p);
+    } else {
+      hipLaunchKernelGGL(scan_wide<false>, dim3(nq, nchunks), dim3(WIDE_THREADS), 0, st, ix->wcodes.p, m, k,
+                         ix->tables.p, from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff,
+                         ix->part_v.p, ix->part_i.p);
+    }
+    HIP_CHECK(hipGetLastError());
+    launch_merge(final_out, ix->part_v.p, ix->part_i.p, lists, (long long)keff, (long long)lists * keff, nq, K,
+                 final_out ? d_oi + (size_t)q0 * K : nullptr, final_out ? d_od + (size_t)q0 * K : nullptr,
+                 final_out && d_oc ? d_oc + q0 : nullptr, final_out && flags ? flags + q0 : nullptr,
+                 final_out ? nullptr : d_pv + (size_t)q0 * keff, final_out ? nullptr : d_pi + (size_t)q0 * keff, st);
+  }
+}
+
+}  // namespace gulon

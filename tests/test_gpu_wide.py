@@ -1,0 +1,107 @@
+"""More than 256 centroids per quantizer: the 10/12/16-bit codes of Coder.BytePlus
+(Coder.scala:99-127,142-168; ProductQuantizer.coderFactory) through the wide-code path
+(wide.hip) -- tables, distances and neighbour ids against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import bits
+from test_gpu_query import _check, _make
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gulon_amd
+    assert gulon_amd.native.device_count() >= 1
+    return gulon_amd
+
+
+@pytest.mark.parametrize("d,m,k,B", [(16, 4, 257, 5), (64, 16, 1024, 3), (30, 7, 1000, 4), (12, 3, 4097, 2)])
+def test_prepare_query_wide_bit_exact(oracle, g, d, m, k, B):
+    rng = np.random.default_rng(k)
+    cents = rng.standard_normal(k * d).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    assert np.array_equal(bits(g.prepare_query(pq, Q)), bits(oracle.prepare_query(cents, d, m, k, Q)))
+
+
+@pytest.mark.parametrize("n,d,m,k,B,K,frm,until", [
+    (20000, 32, 8, 257, 9, 10, 0, None),            # width 10, table in LDS
+    (30000, 64, 16, 1024, 7, 10, 0, None),          # width 10, 64 KiB table
+    (10000, 16, 4, 4096, 5, 5, 0, None),            # width 12
+    (8000, 48, 12, 5000, 4, 10, 0, None),           # width 16, table gathered from memory (240 KB)
+    (3000, 12, 3, 65536, 3, 3, 0, None),            # the largest code book
+    (25000, 30, 7, 300, 6, 1, 1234, 20001),         # ragged m, sub-range with partial first and last block
+    (9000, 20, 5, 777, 70, 63, 0, None),            # largest K, ragged batch
+    (40, 8, 2, 300, 3, 10, 0, None),                # fewer rows than one block; K <= n
+    (7, 8, 2, 300, 2, 10, 0, None),                 # fewer rows than K
+])
+def test_wide_query_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + k)
+    assert enc.coder.width in (10, 12, 16)
+    Q = np.random.default_rng(5).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    res = ix.batch_query(K, Q, frm, until)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    _check(oracle, res, oi, od, oc)
+    ix.close()
+
+
+def test_wide_ties_are_flagged_not_replayed(oracle, g):
+    n, d, m, k, B, K = 12000, 16, 4, 1000, 6, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=3, dup=2000)
+    ix = g.PQIndex(pq, enc)
+    Q = np.stack([ix.decode(r) for r in range(0, 2000, 2000 // B)][:B]).astype(np.float32)
+    oi, od, oc, of = ix.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    assert np.array_equal(bits(od), bits(ed)) and np.array_equal(oc, ec)
+    assert ((of & 3) != 0).all() and ((of & 4) == 0).all()     # tie flags, no exact replay for wide codes
+    for q in range(B):                                         # same rows up to the order inside tie groups
+        if not (of[q] & 1):
+            assert sorted(oi[q].tolist()) == sorted(ei[q].tolist())
+
+
+def test_wide_sharded_equals_unsharded(g):
+    from test_gpu_shared_bounds import _same, sharded_query
+    n, d, m, k, B, K = 90000, 32, 8, 600, 20, 10
+    rng = np.random.default_rng(8)
+    cents = rng.standard_normal(k * d).astype(np.float32)
+    idx = rng.integers(0, k, (m, n)).astype(np.int32)
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    coder = pq.coder_factory(n)
+    enc = g.EncodedMatrix(coder, [coder.build_code(idx[j]) for j in range(m)])
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    full = g.PQIndex(pq, enc).batch_query_raw(K, Q)
+    _same(sharded_query(g, pq, enc, n, 3, Q, K), full)
+
+
+def test_pq_train_encode_query_wide_end_to_end(oracle, g):
+    """ProductQuantizer.apply with numClusters = 300 (width-10 codes) -> encode -> index -> query."""
+    n, d, m, k, iters, B, K = 4000, 12, 3, 300, 3, 8, 5
+    X = oracle.synth(n, d, 3, 11, 40)
+    dm = g.DeviceMatrix.from_host(X)
+    pq = g.ProductQuantizer.apply(dm, g.ProductQuantizerConfig(k, m, iters))
+    cents, _, _ = oracle.pq_train(X, m, k, iters)
+    assert np.array_equal(bits(pq.flat_centroids()), bits(cents))
+    enc = pq.encode(dm)
+    idx = oracle.pq_encode(X, m, k, cents)
+    assert np.array_equal(enc.indices(), idx)
+    for j in range(m):
+        assert np.array_equal(enc.encodings[j], oracle.coder_build(10, idx[j]))
+    Q = X[::n // B][:B]
+    res = g.PQIndex(pq, enc).batch_query(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    _check(oracle, res, oi, od, oc)
+
+
+def test_grouped_index_rejects_wide_codes(g):
+    n, d, m, k = 3000, 8, 2, 300
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    dm = g.DeviceMatrix.from_host(X)
+    coarse = g.KMeans.compute_clusters(g.Vectors(dm), g.KMeansConfig(4, 2))
+    gv = g.group(dm, coarse)
+    pq = g.ProductQuantizer.from_flat(k, d, m, rng.standard_normal(k * d).astype(np.float32))
+    with pytest.raises(NotImplementedError):
+        g.Index.grouped(gv, pq, g.LimitGroups(2))
