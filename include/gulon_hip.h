@@ -160,7 +160,10 @@ int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, int32_t k,
                             int32_t b, float *t_out);
 /* PQIndex(productQuantizer, data) (Index.scala:385-391): copies the m packed code
  * arrays (each gulon_coder_bytes(width,n) bytes, back to back) and the codebooks
- * to HBM.  row_base is added to every returned row id (row sharding). */
+ * to HBM.  row_base is added to every returned row id (row sharding).
+ * Every code width of ProductQuantizer.coderFactory: k <= 256 (widths 0/2/4/8) runs the
+ * byte-coded kernels; 256 < k <= 65536 (Coder.BytePlus, widths 10/12/16) the wide-code path
+ * (exact scan, k_nn <= GULON_MAX_K, tie flags without GULON_FLAG_EXACT_REPLAY). */
 int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
                            const float *cents, int32_t row_base, gulon_index **out);
 int32_t gulon_index_destroy(gulon_index *idx);
