@@ -110,7 +110,43 @@ class OracleEngine:
             of[r] = int(of[r]) | 4                                # GULON_FLAG_EXACT_REPLAY
 
 
-def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0):
+class BoundedOracleEngine(OracleEngine):
+    """The two halves of the scan with shared pruning bounds (gulon_index_scan_bounds_dev /
+    gulon_index_scan_partial_bounded_dev): sample distances out, then only rows within the bound of the
+    union of all shards' samples -- the partial list may come back shorter than K+1."""
+
+    def _all(self, q):
+        T = self.o.prepare_query(self.cents, self.d, self.idx.shape[0], self.k, q.numpy())
+        m, n = self.idx.shape
+        acc = np.zeros((q.shape[0], n), np.float32)
+        for j in range(m):                                        # the reference's order: j ascending, fp32
+            acc = (acc + T[:, j, self.idx[j]]).astype(np.float32)
+        return acc
+
+    def scan_bounds(self, q, b, k, bd):
+        d = np.sort(self._all(q)[:, ::7], axis=1)[:, :k + 1]      # every 7th row is the sample
+        v = np.full((b, k + 1), np.inf, np.float32)
+        v[:, :d.shape[1]] = d
+        bd.copy_(torch.from_numpy(v))
+        self.pending = (b, k)
+
+    def scan_partial_bounded(self, q, b, k, abd, lists, pv, pi):
+        assert self.pending == (b, k)
+        tau = np.sort(abd.numpy().reshape(lists, b, k + 1).transpose(1, 0, 2).reshape(b, -1), axis=1)[:, k]
+        acc = self._all(q)
+        v = np.full((b, k + 1), np.inf, np.float32)
+        i = np.full((b, k + 1), INT_MAX, np.int32)
+        for r in range(b):
+            keep = np.nonzero(acc[r] <= tau[r])[0]
+            order = keep[np.lexsort((keep, acc[r, keep]))][:k + 1]
+            v[r, :len(order)] = acc[r, order]
+            i[r, :len(order)] = order + self.row_base
+        self.shortest = int(min((i[r] != INT_MAX).sum() for r in range(b)))
+        pv.copy_(torch.from_numpy(v))
+        pi.copy_(torch.from_numpy(i))
+
+
+def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0, bounded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -125,8 +161,10 @@ def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0):
         idx[:, -dup:] = idx[:, :dup]          # identical codes in the first and the last shard: distance ties
     Q = rng.standard_normal((B, d)).astype(np.float32)
     lo, hi = shard_bounds(n, world, rank)
-    eng = OracleEngine(oracle, np.ascontiguousarray(idx[:, lo:hi]), d, k, cents, lo, cap=-(-n // world))
+    eng = (BoundedOracleEngine if bounded else OracleEngine)(oracle, np.ascontiguousarray(idx[:, lo:hi]), d, k, cents, lo,
+                                                             cap=-(-n // world))
     sh = ShardedIndex(eng, n, rank, world, dist)
+    assert sh.share_bounds == bounded
     oi, od, oc, of = sh.batch_query(K, Q)
     ei, ed, ec = oracle.pq_batch_query(idx, d, k, cents, Q, K)
     ok = bool(np.array_equal(od.view(np.uint32), ed.view(np.uint32)) and np.array_equal(oc, ec))
@@ -156,6 +194,22 @@ def test_sharded_query_equals_unsharded(world, n):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, 12, 4, 16, 5, 7, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1
+
+
+@pytest.mark.parametrize("world,n,dup", [(2, 3001, 0), (3, 2000, 0), (2, 900, 300)])
+def test_sharded_query_with_shared_bounds(world, n, dup):
+    """Three collectives per batch: bounds, partial lists, replay candidates (sharded.ShardedIndex with an
+    engine that splits its scan) -- results equal the unsharded oracle, also under ties."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 8, 2, 16, 4, 5, out, dup, True)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
