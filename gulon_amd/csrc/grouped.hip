@@ -30,6 +30,7 @@ struct gulon_grouped_index {
   int32_t n = 0, d = 0, g = 0;
   DevBuf<float> gcent, gcent_t;    // [g][d] centroids of the non-empty groups, and the [d][g] transpose
   DevBuf<int> bounds;              // [g+1] first row of every group, then n
+  DevBuf<uint16_t> codes2;         // [n/64][ceil(m/2)][64]: the codes of quantizers 2h (low byte) and 2h+1 (gq_scan_qm)
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
   DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok;
@@ -407,6 +408,178 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void gq_group_scan(const uint8_t *__
   }
 }
 
+// ---- the same (LITERAL = false) result, quantizer-major ------------------------------------------
+// gq_group_scan keeps a whole 16 KiB table per (query, group) pair in LDS: 8 waves per CU, one
+// workgroup barrier per quantizer for 4 pairs, and most of the time is latency.  Here a workgroup is 8
+// pairs (one wave each) and walks the quantizers two at a time: the two codebook slices are staged once
+// for all pairs of the workgroup (double-buffered, one barrier per step), every wave builds only the 2 x 256 table
+// entries of its pair for these two quantizers (2 KiB) and adds them straight onto per-row partial sums
+// held in registers -- up to 32 row blocks (2048 rows) of the group; longer groups take further passes.
+// The sums still grow in the reference's order (j ascending, unfused fp32).  52 KiB of LDS per workgroup
+// at d = 128: three workgroups = 24 waves per CU.  Codes come from a second layout with the bytes of
+// quantizers 2h and 2h + 1 of a row side by side (one 2-byte load per row and step).
+constexpr int QM_WAVES = 8;       // 76 VGPRs allow 6 waves per SIMD: three workgroups of 8 waves (52 KiB each at d = 128) per CU
+constexpr int QM_PARTS = QM_WAVES * 64 / 256;   // staging threads per centroid
+constexpr int QM_RB = 32;      // row blocks whose partial sums a wave holds
+constexpr int QM_LB = 8;       // code words in flight
+
+__global__ void gq_pair_codes(const uint8_t *__restrict__ codes /*[n/64][ng][64][vec]*/, int ng, int vec, int m, int mh,
+                              uint16_t *__restrict__ out /*[n/64][mh][64]*/, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int lane = (int)(t & 63);
+  const long long bh = t >> 6;
+  const int h = (int)(bh % mh);
+  const long long rb = bh / mh;
+  auto byte_of = [&](int j) -> uint32_t {
+    if (j >= m) return 0u;
+    return codes[(((size_t)rb * ng + j / vec) * 64 + lane) * vec + j % vec];
+  };
+  out[t] = (uint16_t)(byte_of(2 * h) | (byte_of(2 * h + 1) << 8));
+}
+
+template <int XS>   // centroid components per staging thread and quantizer: sub-vectors up to QM_PARTS * XS wide
+__global__ __launch_bounds__(64 * QM_WAVES) void gq_scan_qm(
+    const uint16_t *__restrict__ codes2, int mh, int m, int k, int d, const float *__restrict__ pq_cents,
+    const int *__restrict__ from, const int *__restrict__ sdim, const float *__restrict__ gcent,
+    const int *__restrict__ bounds, const float *__restrict__ Q, const int *__restrict__ nn, int nn_stride,
+    const int *__restrict__ nn_cnt, int stride, int K, int *__restrict__ hk, float *__restrict__ hv,
+    int *__restrict__ hs, int smax) {
+  extern __shared__ float qm_lds[];
+  __shared__ int s_npass;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbq = smax * 256;                       // floats of one staged codebook slice, [x][256]
+  float *cb = qm_lds;                               // [2 buffers][2 quantizers][cbq]
+  float *T2 = qm_lds + 4 * (size_t)cbq + (size_t)wave * (512 + d);
+  float *res = T2 + 512;
+  const int q = blockIdx.y;
+  const int t = blockIdx.x * QM_WAVES + wave;       // searched-group slot of this wave
+  const bool live = t < nn_cnt[q];                  // wave-uniform; dead waves still help staging
+  const int c = live ? nn[(size_t)q * nn_stride + t] : 0;
+  const int row_from = live ? bounds[c] : 0, row_until = live ? bounds[c + 1] : 0;
+  const int rb_first = row_from / 64;
+  const int nrb_total = live ? (row_until + 63) / 64 - rb_first : 0;
+  if (tid == 0) s_npass = 0;
+  __syncthreads();
+  if (lane == 0 && nrb_total > 0) atomicMax(&s_npass, (nrb_total + QM_RB - 1) / QM_RB);
+  if (live)
+    for (int e = lane; e < d; e += 64) res[e] = Q[(size_t)q * d + e] - gcent[(size_t)c * d + e];   // MathUtils.subtract
+  __syncthreads();
+  const int npass = s_npass;
+  const int nsteps = (m + 1) / 2;
+  const int cc = tid & 255, part = tid >> 8;        // staging: centroid cc, components part, part + QM_PARTS, ...
+  auto fetch = [&](int step, float (&dst)[2][XS]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+      const int j = 2 * step + jj;
+      const int fr = j < m ? from[j] : 0, sj = j < m ? sdim[j] : 0;
+      const float *cent = pq_cents + (size_t)k * fr + (size_t)cc * sj;
+#pragma unroll
+      for (int u = 0; u < XS; u++) {
+        const int x = part + QM_PARTS * u;
+        dst[jj][u] = (cc < k && x < sj) ? cent[x] : 0.f;
+      }
+    }
+  };
+  auto store = [&](int buf, const float (&src)[2][XS]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int u = 0; u < XS; u++) {
+        const int x = part + QM_PARTS * u;
+        if (x < smax) cb[(size_t)(buf * 2 + jj) * cbq + x * 256 + cc] = src[jj][u];
+      }
+  };
+  const int keff = K + 1;
+  WaveList wl;
+  wl.init();
+  int cnt = 0, saw_nan = 0;
+  for (int pass = 0; pass < npass; pass++) {
+    const int rb0 = rb_first + pass * QM_RB;
+    const int nrb = min(max(nrb_total - pass * QM_RB, 0), QM_RB);
+    float acc[QM_RB];
+#pragma unroll
+    for (int i = 0; i < QM_RB; i++) acc[i] = 0.f;    // PQIndex.distances: j ascending, unfused fp32
+    float pre[2][XS];
+    fetch(0, pre);
+    store(0, pre);             // (every wave left the previous pass through its last barrier)
+    __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+      const int buf = step & 1;
+      if (step + 1 < nsteps) fetch(step + 1, pre);
+      if (nrb > 0) {
+        // Index.prepareQuery on the residual, quantizers 2 step and 2 step + 1:
+        // T[c'] = sum_e (r[from_j + e] - cent_j[c'][e])^2, e ascending, unfused
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int j = 2 * step + jj;
+          if (j < m) {
+            const int fr = from[j], sj = sdim[j];
+            const float *sl = cb + (size_t)(buf * 2 + jj) * cbq;
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};      // centroids lane, lane + 64, lane + 128, lane + 192
+            for (int x = 0; x < sj; x++) {
+              const float rx = res[fr + x];
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const float dd = rx - sl[x * 256 + lane + 64 * i];
+                a4[i] += dd * dd;
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) T2[jj * 256 + lane + 64 * i] = a4[i];
+          }
+        }
+        const bool two = 2 * step + 1 < m;
+#pragma unroll
+        for (int b0 = 0; b0 < QM_RB; b0 += QM_LB) {
+          if (b0 < nrb) {
+            uint32_t w[QM_LB];
+#pragma unroll
+            for (int i = 0; i < QM_LB; i++)
+              w[i] = b0 + i < nrb ? (uint32_t)codes2[((size_t)(rb0 + b0 + i) * mh + step) * 64 + lane] : 0u;
+#pragma unroll
+            for (int i = 0; i < QM_LB; i++) {
+              if (b0 + i < nrb) {
+                acc[b0 + i] += T2[w[i] & 255u];
+                if (two) acc[b0 + i] += T2[256 + (w[i] >> 8)];
+              }
+            }
+          }
+        }
+      }
+      if (step + 1 < nsteps) store((step + 1) & 1, pre);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < QM_RB; i++) {
+      if (i < nrb) {
+        const int rb = rb0 + i;
+        const int row = rb * 64 + lane;
+        const bool valid = row >= row_from && row < row_until;
+        const float a = acc[i];
+        if (__ballot(valid && a != a) != 0ull) saw_nan = 1;   // the heap keeps NaNs while it is not full
+        unsigned long long mk = __ballot(valid && (cnt < keff || wl.accepts(a, row)));
+        while (mk) {
+          const int l = __ffsll((long long)mk) - 1;
+          mk &= mk - 1;
+          const float x = readlane_f(a, l);
+          const int r = rb * 64 + l;
+          if (cnt < keff || wl.accepts(x, r)) {
+            wl.insert(x, r, keff, lane);
+            if (cnt < keff) cnt++;
+          }
+        }
+      }
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)q * stride + t) * keff;
+    if (lane < keff) { hk[o + lane] = wl.i; hv[o + lane] = wl.v; }
+    if (lane == 0) hs[(size_t)q * stride + t] = saw_nan;
+  }
+}
+
 // ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
 __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
                                                const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
@@ -599,7 +772,40 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   }
   // fast path for every query, then the literal heaps for the tie-flagged ones (usually none)
   HIP_CHECK(hipMemsetAsync(gx->qcount.p, 0, sizeof(int), st));
-  scan(false, B, nullptr, nullptr);
+  const size_t lds_qm = (4 * (size_t)smax * 256 + (size_t)QM_WAVES * (512 + ix->d)) * sizeof(float);
+  const char *qm_env = getenv("GULON_GROUPED_QM");   // testing aid: 0 = never, 1 = whenever it applies
+  const bool qm_off = qm_env && atoi(qm_env) == 0, qm_force = qm_env && atoi(qm_env) == 1;
+  // (worth it from ~100 searched groups per query on: 10 M rows / LimitGroups(500) 12.6 -> 9.5 ms per batch,
+  //  1 M rows / LimitGroups(50) 2.06 -> 2.20 ms)
+  if (!qm_off && (stride >= 96 || qm_force) && smax <= 16 && lds_qm <= 150 * 1024) {
+    const int mh = (ix->m + 1) / 2;
+    if (gx->codes2.n == 0) {   // second code layout, built once
+      const size_t nblk = (size_t)ceil_div(ix->n, 64);
+      const long long total = (long long)nblk * mh * 64;
+      const size_t padded = (size_t)total + (size_t)QM_RB * mh * 64;   // gq_scan_qm reads whole batches of row blocks
+      gx->codes2.alloc(padded);
+      HIP_CHECK(hipMemsetAsync(gx->codes2.p, 0, padded * sizeof(uint16_t), st));
+      if (total > 0) {
+        hipLaunchKernelGGL(gq_pair_codes, dim3((unsigned)ceil_div(total, 256LL)), dim3(256), 0, st, ix->codes.p, ix->ng,
+                           ix->vec, ix->m, mh, gx->codes2.p, total);
+        HIP_CHECK(hipGetLastError());
+      }
+    }
+#define QM(X)                                                                                                        \
+    {                                                                                                               \
+      auto kern = gq_scan_qm<X>;                                                                                    \
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm));                      \
+      hipLaunchKernelGGL(kern, dim3(ceil_div(stride, QM_WAVES), B), dim3(64 * QM_WAVES), lds_qm, st, gx->codes2.p, mh, \
+                         ix->m, ix->k, ix->d, ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ,    \
+                         gx->nn.p, nn_stride, gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p, smax);          \
+    }
+    if (smax <= 4) QM(2) else if (smax <= 8) QM(4) else if (smax <= 12) QM(6) else QM(8)
+#undef QM
+    HIP_CHECK(hipGetLastError());
+  } else {
+    scan(false, B, nullptr, nullptr);
+  }
   hipLaunchKernelGGL(gq_merge_fast, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K,
                      d_oi, d_od, d_oc, gx->qlist.p, gx->qcount.p);
   HIP_CHECK(hipGetLastError());

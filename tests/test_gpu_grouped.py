@@ -47,7 +47,10 @@ def _oracle_side(oracle, X, coarse, gv, pq, n):
     (20000, 32, 40, 8, 256, 17, 10, 0),
     (8000, 24, 10, 6, 64, 5, 10, 1500),          # duplicated rows: ties inside and across groups
 ])
-def test_grouped_query_equals_reference(oracle, g, n, d, groups, m, k, B, K, dup, strategy, limit):
+@pytest.mark.parametrize("qm", [False, True])
+def test_grouped_query_equals_reference(oracle, g, monkeypatch, n, d, groups, m, k, B, K, dup, strategy, limit, qm):
+    if qm:      # the quantizer-major kernel normally takes over from ~100 searched groups per query on
+        monkeypatch.setenv("GULON_GROUPED_QM", "1")
     X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + d, dup=dup)
     R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
     strat = g.LimitGroups(limit) if strategy == "groups" else g.LimitVectors(limit)
@@ -59,6 +62,30 @@ def test_grouped_query_equals_reference(oracle, g, n, d, groups, m, k, B, K, dup
     oi, od, oc = index.batch_query_raw(K, Q)
     ei, ed, ec = oracle.grouped_query(codes, d, k, pq.flat_centroids(), cents, offsets, Q, K,
                                       0 if strategy == "groups" else 1, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
+    index.close()
+
+
+@pytest.mark.parametrize("n,d,groups,m,k,limit", [
+    (20000, 16, 3, 4, 256, 3),        # ~6700-row groups: several passes of 32 row blocks
+    (9000, 21, 30, 7, 40, 12),        # odd m: the last step has one quantizer; 3-wide sub-vectors
+    (6000, 50, 20, 5, 256, 20),       # 10-wide sub-vectors
+    (6000, 64, 8, 4, 100, 8),         # 16-wide sub-vectors
+    (30000, 32, 200, 8, 256, 120),    # the regime where it is picked without being forced
+])
+def test_quantizer_major_scan_equals_reference(oracle, g, monkeypatch, n, d, groups, m, k, limit):
+    monkeypatch.setenv("GULON_GROUPED_QM", "1")
+    B, K = 7, 10
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + m, dup=600, iters=2)
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    index = g.Index.grouped(gv, pq, g.LimitGroups(limit))
+    rng = np.random.default_rng(3)
+    Q = np.concatenate([X[rng.integers(0, n, B - 1)], (rng.standard_normal((1, d)) * 2).astype(np.float32)])
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, 0, limit)
     assert np.array_equal(oc, ec)
     for q in range(B):
         assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
