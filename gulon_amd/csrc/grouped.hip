@@ -33,7 +33,7 @@ struct gulon_grouped_index {
   DevBuf<uint16_t> codes2;         // [n/64][ceil(m/2)][64]: the codes of quantizers 2h (low byte) and 2h+1 (gq_scan_qm)
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
-  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok;
+  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok, nn_sized;
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
 };
@@ -423,6 +423,41 @@ constexpr int QM_PARTS = QM_WAVES * 64 / 256;   // staging threads per centroid
 constexpr int QM_RB = 32;      // row blocks whose partial sums a wave holds
 constexpr int QM_LB = 8;       // code words in flight
 
+// The pairs of a workgroup walk the quantizers in lockstep (one barrier per step), so a workgroup is as slow
+// as its largest group: give it groups of similar size.  Per query, the searched groups sorted by their
+// number of row blocks, largest first (any order of the groups gives the same merged list).
+__global__ __launch_bounds__(256) void gq_sort_by_size(const int *__restrict__ nn, int nn_stride,
+                                                       const int *__restrict__ nn_cnt, const int *__restrict__ bounds,
+                                                       int npad /* power of two >= every count, <= 2048 */,
+                                                       int *__restrict__ out) {
+  extern __shared__ unsigned long long gs_keys[];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int cnt = nn_cnt[q];
+  for (int e = tid; e < npad; e += 256) {
+    unsigned long long key = ~0ull;                      // padding sorts last
+    if (e < cnt) {
+      const int c = nn[(size_t)q * nn_stride + e];
+      const unsigned size = (unsigned)(bounds[c + 1] - bounds[c]);
+      key = ((unsigned long long)(0xFFFFFFFFu - size) << 32) | (unsigned)c;
+    }
+    gs_keys[e] = key;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= npad; k2 <<= 1)
+    for (int j = k2 >> 1; j >= 1; j >>= 1) {
+      for (int e = tid; e < npad; e += 256) {
+        const int p = e ^ j;
+        if (p > e) {
+          const unsigned long long a = gs_keys[e], b = gs_keys[p];
+          const bool up = (e & k2) == 0;
+          if ((a > b) == up) { gs_keys[e] = b; gs_keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int e = tid; e < cnt; e += 256) out[(size_t)q * nn_stride + e] = (int)(gs_keys[e] & 0xFFFFFFFFull);
+}
+
 __global__ void gq_pair_codes(const uint8_t *__restrict__ codes /*[n/64][ng][64][vec]*/, int ng, int vec, int m, int mh,
                               uint16_t *__restrict__ out /*[n/64][mh][64]*/, long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,17 +552,21 @@ __global__ __launch_bounds__(64 * QM_WAVES) void gq_scan_qm(
           if (j < m) {
             const int fr = from[j], sj = sdim[j];
             const float *sl = cb + (size_t)(buf * 2 + jj) * cbq;
-            float a4[4] = {0.f, 0.f, 0.f, 0.f};      // centroids lane, lane + 64, lane + 128, lane + 192
+            // centroids lane, lane + 64 | lane + 128, lane + 192: two per packed-fp32 instruction
+            // (v_pk_add_f32 / v_pk_mul_f32 round each half like the scalar instruction: still unfused)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
             for (int x = 0; x < sj; x++) {
               const float rx = res[fr + x];
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                const float dd = rx - sl[x * 256 + lane + 64 * i];
-                a4[i] += dd * dd;
-              }
+              const f32x2 r2 = {rx, rx};
+              const f32x2 c01 = {sl[x * 256 + lane], sl[x * 256 + lane + 64]};
+              const f32x2 c23 = {sl[x * 256 + lane + 128], sl[x * 256 + lane + 192]};
+              const f32x2 d01 = r2 - c01, d23 = r2 - c23;
+              a01 += d01 * d01;
+              a23 += d23 * d23;
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) T2[jj * 256 + lane + 64 * i] = a4[i];
+            T2[jj * 256 + lane] = a01.x; T2[jj * 256 + lane + 64] = a01.y;
+            T2[jj * 256 + lane + 128] = a23.x; T2[jj * 256 + lane + 192] = a23.y;
           }
         }
         const bool two = 2 * step + 1 < m;
@@ -775,9 +814,9 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   const size_t lds_qm = (4 * (size_t)smax * 256 + (size_t)QM_WAVES * (512 + ix->d)) * sizeof(float);
   const char *qm_env = getenv("GULON_GROUPED_QM");   // testing aid: 0 = never, 1 = whenever it applies
   const bool qm_off = qm_env && atoi(qm_env) == 0, qm_force = qm_env && atoi(qm_env) == 1;
-  // (worth it from ~100 searched groups per query on: 10 M rows / LimitGroups(500) 12.6 -> 9.5 ms per batch,
-  //  1 M rows / LimitGroups(50) 2.06 -> 2.20 ms)
-  if (!qm_off && (stride >= 96 || qm_force) && smax <= 16 && lds_qm <= 150 * 1024) {
+  // (from two workgroups of pairs per query on: 10 M rows / LimitGroups(500) 12.6 -> 8.4 ms per batch,
+  //  1 M rows / LimitGroups(50) 2.06 -> 1.92 ms)
+  if (!qm_off && (stride >= 2 * QM_WAVES || qm_force) && smax <= 16 && lds_qm <= 150 * 1024) {
     const int mh = (ix->m + 1) / 2;
     if (gx->codes2.n == 0) {   // second code layout, built once
       const size_t nblk = (size_t)ceil_div(ix->n, 64);
@@ -791,6 +830,16 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
         HIP_CHECK(hipGetLastError());
       }
     }
+    const int *nn_qm = gx->nn.p;
+    if (stride >= 2 * QM_WAVES && stride <= 2048) {   // several workgroups per query: size-sorted groups
+      int npad = 1;
+      while (npad < stride) npad <<= 1;
+      gx->nn_sized.ensure((size_t)B * nn_stride);
+      hipLaunchKernelGGL(gq_sort_by_size, dim3(B), dim3(256), (size_t)npad * sizeof(unsigned long long), st, gx->nn.p,
+                         nn_stride, gx->nn_cnt.p, gx->bounds.p, npad, gx->nn_sized.p);
+      HIP_CHECK(hipGetLastError());
+      nn_qm = gx->nn_sized.p;
+    }
 #define QM(X)                                                                                                        \
     {                                                                                                               \
       auto kern = gq_scan_qm<X>;                                                                                    \
@@ -798,7 +847,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm));                      \
       hipLaunchKernelGGL(kern, dim3(ceil_div(stride, QM_WAVES), B), dim3(64 * QM_WAVES), lds_qm, st, gx->codes2.p, mh, \
                          ix->m, ix->k, ix->d, ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ,    \
-                         gx->nn.p, nn_stride, gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p, smax);          \
+                         nn_qm, nn_stride, gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p, smax);             \
     }
     if (smax <= 4) QM(2) else if (smax <= 8) QM(4) else if (smax <= 12) QM(6) else QM(8)
 #undef QM

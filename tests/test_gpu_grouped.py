@@ -49,7 +49,7 @@ def _oracle_side(oracle, X, coarse, gv, pq, n):
 ])
 @pytest.mark.parametrize("qm", [False, True])
 def test_grouped_query_equals_reference(oracle, g, monkeypatch, n, d, groups, m, k, B, K, dup, strategy, limit, qm):
-    if qm:      # the quantizer-major kernel normally takes over from ~100 searched groups per query on
+    if qm:      # the quantizer-major kernel normally takes over from 16 searched groups per query on
         monkeypatch.setenv("GULON_GROUPED_QM", "1")
     X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + d, dup=dup)
     R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
