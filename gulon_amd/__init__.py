@@ -10,8 +10,11 @@ from .matrix import DeviceMatrix, Matrix
 from .product_quantizer import EncodedMatrix, ProductQuantizer, Quantizer
 from .product_quantizer import Config as ProductQuantizerConfig
 from .vectors import Vectors, subvector_bounds, subvectors
+from .word_vectors import (GroupedWordVectors, KeyedIndex, KeyIndexGrouped, KeyIndexSorted, WordVectors,
+                           read_word2vec)
 
 __all__ = ["native", "GroupedIndex", "GroupedVectors", "LimitGroups", "LimitVectors", "group", "Coder", "width_for_clusters", "Index", "PQIndex", "Result", "SortedIndex",
            "exact_nearest_neighbours", "prepare_query", "KMeans", "KMeansConfig", "DeviceMatrix", "Matrix",
            "EncodedMatrix", "ProductQuantizer", "Quantizer", "ProductQuantizerConfig", "Vectors",
-           "subvector_bounds", "subvectors"]
+           "subvector_bounds", "subvectors", "GroupedWordVectors", "KeyedIndex", "KeyIndexGrouped", "KeyIndexSorted",
+           "WordVectors", "read_word2vec"]
