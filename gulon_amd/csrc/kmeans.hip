@@ -636,6 +636,8 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
   int blocks = ceil_div(nchunks, 4);
   long long ngroups = ceil_div(nchunks, SCAN_GROUP);
   size_t shm = sizeof(unsigned) * 4 * (size_t)k;
+  GULON_UNSUPPORTED(shm > 160 * 1024, "k-means update with k = %d clusters needs %zu B of LDS for its per-cluster counters "
+                    "(> 160 KiB): train at most 10240 clusters per quantizer on the GPU", k, shm);
   hipLaunchKernelGGL(sort_hist, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k);
   hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256), np), dim3(256), 0, st, d_descs,
                      nchunks, k);

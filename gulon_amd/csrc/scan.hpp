@@ -29,6 +29,7 @@ struct gulon_index {
   DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
   bool wide = false;       // k > 256: 16-bit codes, tables in HBM (wide.hip)
   DevBuf<uint16_t> wcodes; // wide: [n/64][m][64]
+  DevBuf<float> wpartial;  // wide, sliced tables: running sums [queries of the sub-batch][rows]
   DevBuf<float> cents;     // k*d
   DevBuf<int> from, sdim;  // m
   // scratch, grown on demand under `mu`

@@ -11,8 +11,10 @@
 //            64 codes with one coalesced 128-byte load;
 //   tables   fp32 [query][m][k] in HBM (built per sub-batch of queries, <= 1 GiB at a time);
 //   scan     one workgroup (8 waves) per (query, chunk of row blocks): the query's table in LDS when
-//            m * k * 4 B fits 128 KiB, else gathered from L2/HBM; lane = row; every wave keeps its own
-//            sorted top-(K+1) list in registers (WaveList), written out as one partial list per wave;
+//            m * k * 4 B fits 128 KiB; larger tables in slices of as many quantizers as fit, one launch per
+//            slice with the running sums parked in HBM in between; k > 32 768 (one quantizer = 256 KiB)
+//            gathered from L2/HBM; lane = row; every wave keeps its own sorted top-(K+1) list in
+//            registers (WaveList), written out as one partial list per wave;
 //   merge    the common merge_lists of scan.hip (ties flagged; the exact TopKHeap replay of tied
 //            queries is not built for wide codes: their flags come back without GULON_FLAG_EXACT_REPLAY).
 #include "scan.hpp"
@@ -60,22 +62,32 @@ __global__ __launch_bounds__(256) void build_tables_wide(const float *__restrict
   T[((size_t)ql * m + j) * k + c] = acc;
 }
 
-template <bool LDS_T>
+// Quantizers [j0, j1) of the table are used by this launch.  LDS_T: that slice is staged in LDS.
+// A table too large for LDS as a whole is walked in slices, one launch per slice: the running sums of
+// every (query, row) go through `partial` ([query][rows of the range], HBM) between the launches --
+// still the reference's order, j ascending -- and only the last launch selects.
+template <bool LDS_T, bool FIRST, bool LAST>
 __global__ __launch_bounds__(WIDE_THREADS) void scan_wide(const uint16_t *__restrict__ codes, int m, int k,
                                                           const float *__restrict__ tables, int row_from,
                                                           int row_until, int row_base, int rb_begin, int rb_total,
                                                           int rb_per_chunk, int nchunks, int keff,
-                                                          float *__restrict__ part_v, int *__restrict__ part_i) {
+                                                          float *__restrict__ part_v, int *__restrict__ part_i,
+                                                          int j0, int j1, float *__restrict__ partial) {
   extern __shared__ float wide_lds[];
+  if (FIRST) j0 = 0;       // (constants for the optimiser: the one-slice instantiation is the plain scan)
+  if (LAST) j1 = m;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = blockIdx.x, chunk = blockIdx.y;
   const float *T = tables + (size_t)q * m * k;
   if (LDS_T) {
-    for (int e = tid; e < m * k; e += WIDE_THREADS) wide_lds[e] = T[e];
+    const float *src = T + (size_t)j0 * k;
+    for (int e = tid; e < (j1 - j0) * k; e += WIDE_THREADS) wide_lds[e] = src[e];
     __syncthreads();
   }
-  const float *tab = LDS_T ? wide_lds : T;
+  const float *tab = LDS_T ? wide_lds : T + (size_t)j0 * k;     // tab[(j - j0) * k + c] for j in [j0, j1)
+  constexpr bool first = FIRST, last = LAST;      // slice [0, ..) starts the sums, slice [.., m) selects
+  float *pq = (first && last) ? nullptr : partial + (size_t)q * rb_total * 64;
   WaveList wl;
   wl.init();
   int cnt = 0;
@@ -83,16 +95,20 @@ __global__ __launch_bounds__(WIDE_THREADS) void scan_wide(const uint16_t *__rest
   for (int e = e0 + wave; e < e1; e += WIDE_NW) {
     const int rb = rb_begin + e;
     const uint16_t *p = codes + (size_t)rb * m * 64 + lane;
-    float acc = 0.f;                                 // the reference's order: j ascending, unfused fp32
-    int j = 0;
-    for (; j + 4 <= m; j += 4) {
+    float acc = first ? 0.f : pq[(size_t)e * 64 + lane];   // the reference's order: j ascending, unfused fp32
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
       const int c0 = p[(size_t)(j + 0) * 64], c1 = p[(size_t)(j + 1) * 64];
       const int c2 = p[(size_t)(j + 2) * 64], c3 = p[(size_t)(j + 3) * 64];
-      const float t0 = tab[(size_t)(j + 0) * k + c0], t1 = tab[(size_t)(j + 1) * k + c1];
-      const float t2 = tab[(size_t)(j + 2) * k + c2], t3 = tab[(size_t)(j + 3) * k + c3];
+      const float t0 = tab[(size_t)(j - j0 + 0) * k + c0], t1 = tab[(size_t)(j - j0 + 1) * k + c1];
+      const float t2 = tab[(size_t)(j - j0 + 2) * k + c2], t3 = tab[(size_t)(j - j0 + 3) * k + c3];
       acc += t0; acc += t1; acc += t2; acc += t3;
     }
-    for (; j < m; j++) acc += tab[(size_t)j * k + p[(size_t)j * 64]];
+    for (; j < j1; j++) acc += tab[(size_t)(j - j0) * k + p[(size_t)j * 64]];
+    if (!last) {
+      pq[(size_t)e * 64 + lane] = acc;
+      continue;
+    }
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
     unsigned long long mk = __ballot(valid && acc <= wl.tau);
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void scan_wide(const uint16_t *__rest
       }
     }
   }
-  if (lane < keff) {
+  if (last && lane < keff) {
     const size_t o = (((size_t)q * nchunks + chunk) * WIDE_NW + wave) * keff + lane;
     part_v[o] = wl.v;
     part_i[o] = wl.i;
@@ -146,8 +162,16 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
   const int keff = K + 1, m = ix->m, k = ix->k;
   const int rb_begin = from / 64, rb_total = ceil_div(until, 64) - rb_begin;
   const size_t table_bytes = (size_t)m * k * sizeof(float);
-  const bool lds_t = table_bytes <= WIDE_LDS_TABLE;
-  const int qb = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, WIDE_TABLE_BYTES / table_bytes));
+  // quantizers per launch: the whole table if it fits LDS; else as many as fit, the running sums going through
+  // HBM between the launches; a single quantizer's k entries above 128 KiB (k > 32 768): gathered through L2
+  const int jp_fit = (int)(WIDE_LDS_TABLE / ((size_t)k * sizeof(float)));
+  const bool lds_t = jp_fit >= 1;
+  const int jp = lds_t ? std::min(jp_fit, m) : m;
+  const int passes = ceil_div(m, jp);
+  const size_t rows_pad = (size_t)rb_total * 64;
+  size_t qb_cap = WIDE_TABLE_BYTES / table_bytes;
+  if (passes > 1) qb_cap = std::min(qb_cap, WIDE_TABLE_BYTES / (rows_pad * sizeof(float)));
+  const int qb = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, qb_cap));
   // chunks: ~2048 workgroups per launch, at least 2 row blocks per wave
   int nchunks = std::max(1, std::min(ceil_div(2048, std::min(qb, B)), rb_total / (2 * WIDE_NW)));
   const int rb_per_chunk = ceil_div(rb_total, nchunks);
@@ -156,21 +180,33 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
   ix->tables.ensure((size_t)qb * m * k);
   ix->part_v.ensure((size_t)qb * lists * keff);
   ix->part_i.ensure((size_t)qb * lists * keff);
+  if (passes > 1) ix->wpartial.ensure((size_t)qb * rows_pad);
   int *flags = d_of;
   for (int q0 = 0; q0 < B; q0 += qb) {
     const int nq = std::min(qb, B - q0);
     launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, m, k, dQ, q0, nq, ix->tables.p, st);
-    if (lds_t) {
-      auto kern = scan_wide<true>;
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)table_bytes));
-      hipLaunchKernelGGL(kern, dim3(nq, nchunks), dim3(WIDE_THREADS), table_bytes, st, ix->wcodes.p, m, k, ix->tables.p,
-                         from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff, ix->part_v.p,
-                         ix->part_i.p);
-    } else {
-      hipLaunchKernelGGL(scan_wide<false>, dim3(nq, nchunks), dim3(WIDE_THREADS), 0, st, ix->wcodes.p, m, k,
-                         ix->tables.p, from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff,
-                         ix->part_v.p, ix->part_i.p);
+    for (int j0 = 0; j0 < m; j0 += jp) {
+      const int j1 = std::min(m, j0 + jp);
+      float *partial = passes > 1 ? ix->wpartial.p : nullptr;
+      const size_t lds_bytes = lds_t ? (size_t)(j1 - j0) * k * sizeof(float) : 0;
+      const bool first = j0 == 0, last = j1 == m;
+#define WIDE_GO(L, F, LA)                                                                                          \
+      {                                                                                                             \
+        auto kern = scan_wide<L, F, LA>;                                                                            \
+        if (lds_bytes)                                                                                              \
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));               \
+        hipLaunchKernelGGL(kern, dim3(nq, nchunks), dim3(WIDE_THREADS), lds_bytes, st, ix->wcodes.p, m, k,           \
+                           ix->tables.p, from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff, \
+                           ix->part_v.p, ix->part_i.p, j0, j1, partial);                                            \
+      }
+      if (!lds_t) WIDE_GO(false, true, true)
+      else if (first && last) WIDE_GO(true, true, true)
+      else if (first) WIDE_GO(true, true, false)
+      else if (last) WIDE_GO(true, false, true)
+      else WIDE_GO(true, false, false)
+#undef WIDE_GO
+      HIP_CHECK(hipGetLastError());
     }
     HIP_CHECK(hipGetLastError());
     launch_merge(final_out, ix->part_v.p, ix->part_i.p, lists, (long long)keff, (long long)lists * keff, nq, K,

@@ -31,7 +31,9 @@ def test_prepare_query_wide_bit_exact(oracle, g, d, m, k, B):
     (30000, 64, 16, 1024, 7, 10, 0, None),          # width 10, 64 KiB table
     (10000, 16, 4, 4096, 5, 5, 0, None),            # width 12
     (8000, 48, 12, 5000, 4, 10, 0, None),           # width 16, table gathered from memory (240 KB)
-    (3000, 12, 3, 65536, 3, 3, 0, None),            # the largest code book
+    (3000, 12, 3, 65536, 3, 3, 0, None),            # the largest code book: one quantizer's entries exceed LDS
+    (6000, 27, 9, 10000, 5, 10, 0, None),           # 40 KB per quantizer: three slices of three (first, middle, last)
+    (9000, 16, 8, 6000, 4, 7, 777, 8100),           # sliced table over a sub-range
     (25000, 30, 7, 300, 6, 1, 1234, 20001),         # ragged m, sub-range with partial first and last block
     (9000, 20, 5, 777, 70, 63, 0, None),            # largest K, ragged batch
     (40, 8, 2, 300, 3, 10, 0, None),                # fewer rows than one block; K <= n
