@@ -386,9 +386,9 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       // rare path.  Its queue addresses are uniform and loop-invariant, and hoisted out of the scan loop
       // they would hold ~60 SGPRs for the whole kernel -- past the 102 that still allow two workgroups per
       // CU.  Opaque copies keep that arithmetic in here.
-      int *cnt_l = cnt, *queue_l = queue;
+      int *cnt_l = cnt, *queue_l = queue, *fb_l = const_cast<int *>(fb_tile);
       int slot_l = slot, tile_l = tile;
-      asm volatile("" : "+s"(cnt_l), "+s"(queue_l), "+s"(slot_l), "+s"(tile_l));
+      asm volatile("" : "+s"(cnt_l), "+s"(queue_l), "+s"(slot_l), "+s"(tile_l), "+s"(fb_l));
 #pragma unroll
       for (int s = 0; s < NQG; s++)
 #pragma unroll
@@ -396,15 +396,19 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
           const uint32_t l = valid ? left[s][x] : 0u;
           if (__ballot(l != 0) == 0ull) continue;
           const int q0 = (tile_l * NQG + s) * QW + 4 * (x >> 1) + (x & 1);
+          // a full sub-queue means the bound separates nothing for this query: flag its tile at once, so that
+          // the workgroups of the tile that have not started yet return immediately (the exact scan redoes it)
           if (l & 0xFFFFu) {
             const int sq = q0 * NSLOT + slot_l;
             const int pos = atomicAdd(&cnt_l[sq], 1);
             if (pos < cap) queue_l[(size_t)sq * cap + pos] = row;
+            else fb_l[q0 / qt] = 1;
           }
           if (l >> 16) {
             const int sq = (q0 + 2) * NSLOT + slot_l;
             const int pos = atomicAdd(&cnt_l[sq], 1);
             if (pos < cap) queue_l[(size_t)sq * cap + pos] = row;
+            else fb_l[(q0 + 2) / qt] = 1;
           }
         }
     }
