@@ -78,7 +78,15 @@ def main():
         if os.environ.get("GULON_BENCH_BACKEND") == "gloo":   # rehearsal of the multi-rank path on one GPU
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # the collectives' kernels queue for compute units like every other launch while a filter kernel
+            # fills the chip: a high-priority stream gets them the units that come free first
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                opts = None
+            kw = {"pg_options": opts} if opts is not None else {}
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw)
     dev = torch.device("cuda", local_rank)
     L = N.lib()
     n, d, m, k, B, K = args.rows, args.dim, args.quantizers, args.clusters, args.batch, args.knn

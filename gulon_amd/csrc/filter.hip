@@ -788,9 +788,12 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ix->fb_hint_d), ix->fb_hint_h, 0));
     }
     // a hint, read without synchronisation: did a recent fallback launch of this index find work?
+    // (launches are enqueued ahead of their execution, so the word lags by the batches in flight: once seen,
+    // it keeps the next 8 launches wide, and every launch that finds work arms it again)
     volatile int *hint = ix->fb_hint_h;
-    const bool wide = *hint != 0;
-    if (wide) *hint = 0;                  // decays unless the wide launch finds work again
+    if (*hint != 0) { *hint = 0; ix->fb_wide_left = 8; }
+    const bool wide = ix->fb_wide_left > 0;
+    if (wide) ix->fb_wide_left--;
     launch_scan(ix, fb_tiles, cfb_n, rb_begin, rb_total, pfb, all, from, until, keff, st, nullptr, nullptr,
                 ix->fb_tile.p, true, wide ? fb_tiles : 8, ix->fb_hint_d);
   }

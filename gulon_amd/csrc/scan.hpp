@@ -63,6 +63,7 @@ struct gulon_index {
   int pend_b = -1, pend_k = -1, pend_from = -1, pend_until = -1;
   // host-mapped word the filter's fallback launch sets when it had anything to do: sizes the next one
   int *fb_hint_h = nullptr, *fb_hint_d = nullptr;
+  int fb_wide_left = 0;   // launches that stay wide after the word was last seen set
   hipEvent_t take_event() {
     if (ev_next == ev_pool.size()) {
       hipEvent_t e = nullptr;

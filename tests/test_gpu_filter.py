@@ -86,6 +86,26 @@ def test_filter_equals_unfiltered_scan(oracle, g, tune):
     ix.close()
 
 
+def test_fallback_launch_width_adapts_over_repeated_batches(oracle, g, tune):
+    """Random codes and a 512-row sample: most query tiles give up and are redone by the exact scan.  The
+    fallback launch starts narrow (8 looping workgroups), turns wide once a launch reported work and stays
+    so -- every batch of the series equals the unfiltered scan."""
+    n, d, m, k, B, K = 200000, 128, 16, 256, 64, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=5)
+    Q = np.random.default_rng(11).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    tune(GULON_SCAN_FILTER=0)
+    ref = ix.batch_query(K, Q)
+    tune(GULON_SCAN_FILTER=1, GULON_FILTER_CAP=64)
+    for _ in range(5):
+        got = ix.batch_query(K, Q)
+        for x, y in zip(got, ref):
+            assert x.rows.tolist() == y.rows.tolist()
+            assert np.array_equal(bits(x.distances), bits(y.distances))
+            assert x.flags == y.flags
+    ix.close()
+
+
 def test_queries_that_are_dataset_rows(oracle, g, tune):
     """A query equal to a centroid combination has distance == sum of the table minima (budget 0)."""
     n, d, m, k, B, K = 50000, 64, 16, 256, 12, 10
