@@ -293,13 +293,15 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
   constexpr int DW = QW / 4;     // dwords per entry
   // The kernel runs at the LDS random-gather floor, and the vector L1 is a second gather
-  // pipe that sits idle: the entries of the first GLB quantizers of a code word are read from the quantized
-  // table in global memory (8 KiB per tile and quantizer pair: L1-resident) instead of its LDS copy.  Measured
-  // on the 10 M-row bench index, main stage alone: 3.00 ms with 0, 2.69 with 2, 2.61 with 3, 2.73 with 4,
-  // 3.29 with 5, 4.74 with 8; two batches in flight 3.44 / 3.21 / 3.23 / 3.36 ms per batch.  It pays only where
+  // pipe that sits idle: the entries of the last GLB quantizers of a code word are read from the quantized
+  // table in global memory (4 KiB per tile and quantizer: L1-resident) instead of its LDS copy, requested at
+  // the top of the row block so that their latency passes under the LDS gathers.  Measured on the 10 M-row
+  // bench index (two batches in flight / main stage alone): 3.44 / 3.00 ms with every entry from LDS,
+  // 3.06 / 2.66 with 2 from L1, 3.04 / 2.57 with 3, 3.06 / 2.66 with 4 (requested where they are used instead
+  // of up front: 3.21, 3.23, 3.36; five 3.96, eight 5.58 -- the L1 path saturates quickly).  It pays only where
   // LDS is the one busy pipe: 16-byte entries, four entries summed per widening, two workgroups per CU (m <= 16);
   // with 4-byte code words, wider indexes (m = 32, 64, 100) or the 7-bit levels it measured 2-50 % slower.
-  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4) ? 2 : 0;
+  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4) ? 3 : 0;
   using Word = typename CodeWord<VEC>::type;
   using QE = typename QEntry<QW>::type;
   extern __shared__ uint4 qlds_raw[];
@@ -353,6 +355,14 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
       const QE *tj_lds = qlds + g * VEC * 256;
       const QE *tj_glb = reinterpret_cast<const QE *>(qtab) + (size_t)tile * NQG * tab + g * VEC * 256;
+      // the L1-served entries are the LAST GLB of the word, requested first: their latency passes under the
+      // LDS gathers of the other entries (byte sums commute)
+      QE gl[GLB > 0 ? GLB : 1][NQG];
+#pragma unroll
+      for (int a = 0; a < GLB; a++)
+#pragma unroll
+        for (int s = 0; s < NQG; s++)
+          gl[a][s] = tj_glb[(VEC - GLB + a) * 256 + code_byte<VEC>(w, VEC - GLB + a) + s * tab];
 #pragma unroll
       for (int b = 0; b < VEC; b += NADD) {
         uint32_t c[NADD];
@@ -360,15 +370,20 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
         for (int a = 0; a < NADD; a++) c[a] = code_byte<VEC>(w, b + a);
 #pragma unroll
         for (int s = 0; s < NQG; s++) {
-          QE x = (b < GLB ? tj_glb : tj_lds)[b * 256 + c[0] + s * tab];
           uint32_t xs[DW];
 #pragma unroll
-          for (int dd = 0; dd < DW; dd++) xs[dd] = reinterpret_cast<const uint32_t *>(&x)[dd];
+          for (int dd = 0; dd < DW; dd++) xs[dd] = 0;
 #pragma unroll
-          for (int a = 1; a < NADD; a++) {   // bytes cannot carry: NADD * QMAX <= 255
-            const QE y = (b + a < GLB ? tj_glb : tj_lds)[(b + a) * 256 + c[a] + s * tab];
+          for (int a = 0; a < NADD; a++) {   // bytes cannot carry: NADD * QMAX <= 255
+            const int e = b + a;
+            if (e >= VEC - GLB) {
 #pragma unroll
-            for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&y)[dd];
+              for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&gl[e - (VEC - GLB)][s])[dd];
+            } else {
+              const QE y = tj_lds[e * 256 + c[a] + s * tab];
+#pragma unroll
+              for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&y)[dd];
+            }
           }
 #pragma unroll
           for (int dd = 0; dd < DW; dd++) {
