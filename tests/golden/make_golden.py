@@ -80,6 +80,16 @@ def main():
     np.savez_compressed(os.path.join(HERE, "grouped_small.npz"), coarse_centroids=Cc, assignments=ga.astype(np.uint8),
                         perm=perm, group_centroids=gcent, offsets=goff, residual_codebooks=rc,
                         residual_codes=ridx.astype(np.uint8), queries=Qg, **out)
+    # 6. more than 256 centroids per quantizer (Coder.BytePlus, width 10): 3000 x 12, m = 3, k = 300
+    wn, wd, wm, wk = 3000, 12, 3, 300
+    Xw = o.synth(wn, wd, 3, 11, 40)
+    wc, wits, wconv = o.pq_train(Xw, wm, wk, 3)
+    widx = o.pq_encode(Xw, wm, wk, wc)
+    Qw = Xw[[0, 17, 1500, 2999]]
+    wi, wdist, wcnt = o.pq_batch_query(widx, wd, wk, wc, Qw, 5)
+    np.savez_compressed(os.path.join(HERE, "pq_wide.npz"), X=Xw, codebooks=wc, iterations=wits, converged=wconv,
+                        codes=widx.astype(np.uint16), packed_q0=o.coder_build(10, widx[0]), queries=Qw,
+                        tables=o.prepare_query(wc, wd, wm, wk, Qw), nn_idx=wi, nn_dist=wdist, nn_count=wcnt)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
