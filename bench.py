@@ -125,7 +125,10 @@ def main():
     # the GPU idle (1.25 M-row shard, one-rank RCCL rehearsal: 0.602 / 0.566 / 0.561 ms for 2 / 3 / 4)
     collective = world > 1 or rehearse
     nfl = args.inflight if args.inflight > 0 else (4 if collective else 2)
-    engines = [HipEngine(pq, shard, lo, dev) for _ in range(nfl)]
+    # ONE copy of the shard's codes in HBM; every further batch in flight is a query context over it
+    # (gulon_index_context_create: its own scratch, the same codes and codebooks)
+    engines = [HipEngine(pq, shard, lo, dev)]
+    engines += [HipEngine(pq, shard, lo, dev, parent=engines[0]) for _ in range(nfl - 1)]
     shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse) for e in engines]
     if collective:
         # side streams only: work on the legacy default stream serialises with the collectives' stream
@@ -149,10 +152,21 @@ def main():
         i = step_no[0] % nfl
         step_no[0] += 1
         with torch.cuda.stream(streams[i]):
+            # the batch this slot ran `nfl` steps ago is consumed first (as a server hands results out): when it
+            # had more tie-flagged queries than the unconditional replay round holds, its further rounds run here
+            extra_rounds[0] += shardeds[i].complete()
             return shardeds[i].batch_query_dev(Q, B, K)
+
+    extra_rounds = [0]
+
+    def drain():
+        for i in range(nfl):
+            with torch.cuda.stream(streams[i]):
+                extra_rounds[0] += shardeds[i].complete()
 
     for _ in range(nfl):
         out_idx, out_dist, out_cnt, out_flg = step()
+    drain()
     torch.cuda.synchronize()
     step_no[0] = 0
 
@@ -164,13 +178,16 @@ def main():
     note("first batches done")
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
+    extra_rounds[0] = 0
     for e in engines:
         N.check(L.gulon_index_profile(e.index._h, 1))
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     enqueue_s = time.perf_counter() - t_start          # host time to enqueue K steps (diagnostic)
     barrier()
     elapsed = time.perf_counter() - t_start

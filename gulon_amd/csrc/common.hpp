@@ -75,15 +75,17 @@ template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  bool owned = true;   // false: a view of another DevBuf's memory (query contexts share an index's codes)
   DevBuf() = default;
   explicit DevBuf(size_t count) { alloc(count); }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
   DevBuf &operator=(DevBuf &&o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
     return *this;
   }
+  void borrow(const DevBuf &o) { release(); p = o.p; n = o.n; owned = false; }
   ~DevBuf() { release(); }
   void alloc(size_t count) {
     release();
@@ -91,7 +93,7 @@ struct DevBuf {
     n = count;
   }
   void ensure(size_t count) { if (count > n) alloc(count); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
   void upload(const T *h, size_t count, hipStream_t st = nullptr) {
     ensure(count);
     if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));

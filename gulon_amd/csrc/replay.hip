@@ -33,7 +33,7 @@ constexpr int RP_LDS_POOL = 16384;   // candidates rp_heap can sort in LDS (all 
 constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = 2048, RP_L1_SEG = 64, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
 
 // Candidate buffer ("pack", int32 words) for F flagged queries with C candidates each:
-//   [0] number of flagged queries (<= F)   [1] F   [2] C   [3] -
+//   [0] flagged queries in this pack (<= F)   [1] F   [2] C   [3] flagged queries of the whole batch
 //   [4, 4+F) query ids, ascending          [4+F, 4+2F) candidates written per query
 //   then F*C distances (float bits), then F*C global row ids.
 // One pack per row shard; rp_heap consumes the packs of all shards of a query together.
@@ -47,23 +47,25 @@ struct Pack {
 };
 size_t replay_pack_words(int F, int C) { return 4 + 2 * (size_t)F + 2 * (size_t)F * C; }
 
-// flagged queries in ascending order (deterministic: every shard builds the same list); one wave
-__global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, int B, Pack pk) {
+// flagged queries in ascending order (deterministic: every shard builds the same list), the first `skip`
+// of them left out (they were replayed by an earlier round); one wave
+__global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, int B, Pack pk, int skip) {
   const int lane = threadIdx.x;
   int base = 0;
   for (int q0 = 0; q0 < B; q0 += 64) {
     const int q = q0 + lane;
     const bool fl = q < B && (flags[q] & (GULON_FLAG_BOUNDARY_TIE | GULON_FLAG_INTERIOR_TIE));
     const unsigned long long mk = __ballot(fl);
-    const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
-    if (fl && pos < pk.F) pk.list()[pos] = q;
+    const int pos = base + __popcll(mk & ((1ull << lane) - 1ull)) - skip;
+    if (fl && pos >= 0 && pos < pk.F) pk.list()[pos] = q;
     base += __popcll(mk);
   }
+  const int here = max(0, min(base - skip, pk.F));
   for (int f = lane; f < pk.F; f += 64) {
     pk.evcnt()[f] = 0;
-    if (f >= base) pk.list()[f] = -1;
+    if (f >= here) pk.list()[f] = -1;
   }
-  if (lane == 0) { pk.count()[0] = min(base, pk.F); pk.count()[1] = pk.F; pk.count()[2] = pk.C; pk.count()[3] = 0; }
+  if (lane == 0) { pk.count()[0] = here; pk.count()[1] = pk.F; pk.count()[2] = pk.C; pk.count()[3] = base; }
 }
 
 __global__ void rp_gather_queries(const float *__restrict__ Q, int d, int maxf, const int *__restrict__ list,
@@ -370,10 +372,10 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
 
 // Candidates of the flagged queries over rows [from, until) of this index (cold start at `from`).
 void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
-                    int C, int *pack, hipStream_t st) {
+                    int C, int *pack, hipStream_t st, int skip = 0) {
   const Pack pk{pack, F, C};
   // (wide codes, k > 256: no replay -- an empty pack, the tie flags stay as the merge set them)
-  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, ix->wide ? 0 : B, pk);
+  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, ix->wide ? 0 : B, pk, skip);
   HIP_CHECK(hipGetLastError());
   if (until <= from || ix->wide) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
@@ -432,7 +434,8 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
 // Literal heap over the candidates of `lists` packs (one per row shard, same flagged-query list).
 void replay_apply(const int *packs, int lists, long long stride_words, int F, int C, int K, int *d_oi, float *d_od,
                   int *d_oc, int *d_of, unsigned long long *dbgp, hipStream_t st) {
-  const int lds_pool = (int)std::min<long long>((long long)lists * C, RP_LDS_POOL);
+  int lds_pool = 64;   // a power of two: the bitonic sort pads the candidates to one
+  while (lds_pool < RP_LDS_POOL && lds_pool < (long long)lists * C) lds_pool <<= 1;
   const size_t heap_lds = (size_t)(2 * lds_pool + 2 * RP_KEEP) * sizeof(float);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rp_heap), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)heap_lds));
@@ -464,33 +467,43 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
 using namespace gulon;
 
 // ---- row-sharded replay (one pack per shard, exchanged by the caller) ------------------------
-GULON_API int64_t gulon_replay_pack_words(void) {
-  return (int64_t)replay_pack_words(GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL);
+namespace {
+void check_pack_shape(int F, int C) {
+  GULON_REQUIRE(F >= 1 && F <= RP_MAXF, "max_flagged must be in [1, %d]", RP_MAXF);
+  GULON_REQUIRE(C >= 64 && C <= RP_POOL, "pool must be in [64, %d]", RP_POOL);
+}
+}  // namespace
+
+GULON_API int64_t gulon_replay_pack_words(int32_t max_flagged, int32_t pool) {
+  if (max_flagged < 1 || max_flagged > RP_MAXF || pool < 64 || pool > RP_POOL) return -1;
+  return (int64_t)replay_pack_words(max_flagged, pool);
 }
 
 GULON_API int32_t gulon_index_replay_collect_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
-                                                 int32_t from, int32_t until, const int32_t *d_flags, int32_t *d_pack,
-                                                 void *stream) {
+                                                 int32_t from, int32_t until, const int32_t *d_flags, int32_t skip,
+                                                 int32_t max_flagged, int32_t pool, int32_t *d_pack, void *stream) {
   return guarded([&] {
     GULON_REQUIRE(idx != nullptr && d_pack != nullptr && d_flags != nullptr, "null argument");
     GULON_REQUIRE(from <= until && from >= 0 && until <= idx->n, "expected: 0 <= from <= until <= length");
-    GULON_REQUIRE(b >= 0 && k_nn >= 1, "bad shape");
+    GULON_REQUIRE(b >= 0 && k_nn >= 1 && skip >= 0, "bad shape");
+    check_pack_shape(max_flagged, pool);
     GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
     std::lock_guard<std::mutex> lock(idx->mu);
-    replay_collect(idx, d_queries, b, k_nn, from, until, d_flags, GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL, d_pack,
-                   (hipStream_t)stream);
+    StreamOrder so(idx, (hipStream_t)stream);
+    replay_collect(idx, d_queries, b, k_nn, from, until, d_flags, max_flagged, pool, d_pack, (hipStream_t)stream, skip);
+    so.done();
   });
 }
 
-GULON_API int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t b, int32_t k_nn,
-                                         int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
-                                         int32_t *d_out_flags, void *stream) {
+GULON_API int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t max_flagged, int32_t pool,
+                                         int32_t b, int32_t k_nn, int32_t *d_out_idx, float *d_out_dist,
+                                         int32_t *d_out_count, int32_t *d_out_flags, void *stream) {
   return guarded([&] {
     GULON_REQUIRE(d_packs != nullptr && lists >= 1 && b >= 0 && k_nn >= 1, "bad arguments");
+    check_pack_shape(max_flagged, pool);
     GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
     GULON_REQUIRE(d_out_idx && d_out_dist && d_out_flags, "null output");
-    replay_apply(d_packs, lists, (long long)replay_pack_words(GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL),
-                 GULON_REPLAY_MAX_FLAGGED, GULON_REPLAY_POOL, k_nn, d_out_idx, d_out_dist, d_out_count, d_out_flags,
-                 nullptr, (hipStream_t)stream);
+    replay_apply(d_packs, lists, (long long)replay_pack_words(max_flagged, pool), max_flagged, pool, k_nn, d_out_idx,
+                 d_out_dist, d_out_count, d_out_flags, nullptr, (hipStream_t)stream);
   });
 }

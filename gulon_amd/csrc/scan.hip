@@ -910,8 +910,72 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
   });
 }
 
+namespace gulon {
+gulon_index *make_context(gulon_index *parent) {
+  std::unique_ptr<gulon_index> c(new gulon_index());
+  c->n = parent->n; c->d = parent->d; c->m = parent->m; c->k = parent->k; c->row_base = parent->row_base;
+  c->vec = parent->vec; c->ng = parent->ng; c->m_pad = parent->m_pad; c->nsub = parent->nsub; c->w = parent->w;
+  c->wide = parent->wide;
+  c->codes.borrow(parent->codes);
+  c->wcodes.borrow(parent->wcodes);
+  c->cents.borrow(parent->cents);
+  c->from.borrow(parent->from);
+  c->sdim.borrow(parent->sdim);
+  return c.release();
+}
+}  // namespace gulon
+
+namespace {
+void release_index(gulon_index *ix) {
+  if (!ix) return;
+  if (ix->refs.fetch_sub(1) != 1) return;       // contexts of this index are still alive
+  gulon_index *parent = ix->parent;
+  delete ix;
+  release_index(parent);
+}
+
+// host-pointer calls: take a free workspace of this handle (the handle itself first), creating up to
+// GULON_HOST_CONTEXTS (default 4) internal contexts; blocks while all are busy
+int host_context_limit() {
+  static const int lim = [] { const char *e = getenv("GULON_HOST_CONTEXTS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+  return lim;
+}
+gulon_index *acquire_host_context(gulon_index *idx) {
+  std::unique_lock<std::mutex> lk(idx->host_mu);
+  for (;;) {
+    if (!idx->host_self_busy) { idx->host_self_busy = true; return idx; }
+    if (!idx->host_free.empty()) { gulon_index *c = idx->host_free.back(); idx->host_free.pop_back(); return c; }
+    if ((int)idx->host_all.size() + 1 < host_context_limit()) {
+      gulon_index *c = make_context(idx);
+      idx->host_all.push_back(c);
+      return c;
+    }
+    idx->host_cv.wait(lk);
+  }
+}
+void release_host_context(gulon_index *idx, gulon_index *c) {
+  {
+    std::lock_guard<std::mutex> lk(idx->host_mu);
+    if (c == idx) idx->host_self_busy = false; else idx->host_free.push_back(c);
+  }
+  idx->host_cv.notify_one();
+}
+}  // namespace
+
 GULON_API int32_t gulon_index_destroy(gulon_index *idx) {
-  return guarded([&] { delete idx; });
+  return guarded([&] { release_index(idx); });
+}
+
+GULON_API int32_t gulon_index_context_create(gulon_index *parent, gulon_index **out) {
+  return guarded([&] {
+    GULON_REQUIRE(parent != nullptr && out != nullptr, "null argument");
+    *out = nullptr;
+    gulon_index *root = parent->parent ? parent->parent : parent;   // contexts of contexts hang off the owner
+    gulon_index *c = make_context(root);
+    c->parent = root;
+    root->refs.fetch_add(1);
+    *out = c;
+  });
 }
 
 GULON_API int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
@@ -920,8 +984,11 @@ GULON_API int32_t gulon_index_batch_query_dev(gulon_index *idx, const float *d_q
   return guarded([&] {
     GULON_REQUIRE(idx != nullptr, "index is null");
     std::lock_guard<std::mutex> lock(idx->mu);
+    idx->pend_b = -1;
+    StreamOrder so(idx, (hipStream_t)stream);
     run_query(idx, d_queries, b, k_nn, from, until, true, d_out_idx, d_out_dist, d_out_count, d_out_flags, nullptr,
               nullptr, (hipStream_t)stream);
+    so.done();
   });
 }
 
@@ -931,8 +998,11 @@ GULON_API int32_t gulon_index_scan_partial_dev(gulon_index *idx, const float *d_
   return guarded([&] {
     GULON_REQUIRE(idx != nullptr, "index is null");
     std::lock_guard<std::mutex> lock(idx->mu);
+    idx->pend_b = -1;
+    StreamOrder so(idx, (hipStream_t)stream);
     run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, d_part_dist,
               d_part_idx, (hipStream_t)stream);
+    so.done();
   });
 }
 
@@ -945,8 +1015,10 @@ GULON_API int32_t gulon_index_scan_bounds_dev(gulon_index *idx, const float *d_q
     std::lock_guard<std::mutex> lock(idx->mu);
     const SharedBounds sb{1, d_bounds, nullptr, 0};
     idx->pend_b = -1;
+    StreamOrder so(idx, (hipStream_t)stream);
     run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
               (hipStream_t)stream, &sb);
+    so.done();
     idx->pend_b = b; idx->pend_k = k_nn; idx->pend_from = from; idx->pend_until = until;
   });
 }
@@ -962,8 +1034,10 @@ GULON_API int32_t gulon_index_scan_partial_bounded_dev(gulon_index *idx, const f
                   "scan_partial_bounded must follow scan_bounds on the same index with the same arguments");
     idx->pend_b = -1;
     const SharedBounds sb{2, nullptr, d_all_bounds, lists};
+    StreamOrder so(idx, (hipStream_t)stream);
     run_query(idx, d_queries, b, k_nn, from, until, false, nullptr, nullptr, nullptr, nullptr, d_part_dist,
               d_part_idx, (hipStream_t)stream, &sb);
+    so.done();
   });
 }
 
@@ -973,23 +1047,30 @@ GULON_API int32_t gulon_index_batch_query(gulon_index *idx, const float *queries
   return guarded([&] {
     GULON_REQUIRE(idx != nullptr, "index is null");
     GULON_REQUIRE(b >= 0 && k_nn >= 0, "k and batch size must be non-negative");
-    std::lock_guard<std::mutex> lock(idx->mu);
+    // concurrent callers (Tests.scala:109-122 queries from a thread pool) each get a workspace of their own
+    gulon_index *c = acquire_host_context(idx);
+    struct Release { gulon_index *i, *c; ~Release() { release_host_context(i, c); } } rel{idx, c};
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->pend_b = -1;
     size_t bk = (size_t)b * (size_t)k_nn;
-    idx->stage_q.ensure((size_t)b * idx->d + 1);
-    idx->stage_oi.ensure(bk + 1);
-    idx->stage_od.ensure(bk + 1);
-    idx->stage_oc.ensure((size_t)b + 1);
-    idx->stage_of.ensure((size_t)b + 1);
-    hipStream_t st = nullptr;
-    if (b > 0) HIP_CHECK(hipMemcpyAsync(idx->stage_q.p, queries, sizeof(float) * (size_t)b * idx->d, hipMemcpyHostToDevice, st));
-    run_query(idx, idx->stage_q.p, b, k_nn, from, until, true, idx->stage_oi.p, idx->stage_od.p, idx->stage_oc.p,
-              idx->stage_of.p, nullptr, nullptr, st);
+    c->stage_q.ensure((size_t)b * c->d + 1);
+    c->stage_oi.ensure(bk + 1);
+    c->stage_od.ensure(bk + 1);
+    c->stage_oc.ensure((size_t)b + 1);
+    c->stage_of.ensure((size_t)b + 1);
+    if (!c->host_stream) HIP_CHECK(hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking));
+    hipStream_t st = c->host_stream;
+    StreamOrder so(c, st);
+    if (b > 0) HIP_CHECK(hipMemcpyAsync(c->stage_q.p, queries, sizeof(float) * (size_t)b * c->d, hipMemcpyHostToDevice, st));
+    run_query(c, c->stage_q.p, b, k_nn, from, until, true, c->stage_oi.p, c->stage_od.p, c->stage_oc.p,
+              c->stage_of.p, nullptr, nullptr, st);
     if (bk) {
-      idx->stage_oi.download(out_idx, bk, st);
-      idx->stage_od.download(out_dist, bk, st);
+      c->stage_oi.download(out_idx, bk, st);
+      c->stage_od.download(out_dist, bk, st);
     }
-    if (b > 0 && out_count) idx->stage_oc.download(out_count, b, st);
-    if (b > 0 && out_flags) idx->stage_of.download(out_flags, b, st);
+    if (b > 0 && out_count) c->stage_oc.download(out_count, b, st);
+    if (b > 0 && out_flags) c->stage_of.download(out_flags, b, st);
+    so.done();
     HIP_CHECK(hipStreamSynchronize(st));
   });
 }

@@ -1,6 +1,8 @@
 // Internal declarations shared by the top-k users (scan, exact kNN).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <memory>
 
 #include "common.hpp"
@@ -64,6 +66,24 @@ struct gulon_index {
   // host-mapped word the filter's fallback launch sets when it had anything to do: sizes the next one
   int *fb_hint_h = nullptr, *fb_hint_d = nullptr;
   int fb_wide_left = 0;   // launches that stay wide after the word was last seen set
+  // ---- query contexts (gulon_index_context_create): a context BORROWS the read-only members of its parent
+  // (codes, wcodes, cents, from, sdim) and owns every scratch buffer above, so batches in flight on
+  // different streams / threads never share device scratch.  The parent stays alive until its last context
+  // is destroyed (refs).
+  gulon_index *parent = nullptr;
+  std::atomic<int> refs{1};
+  // one handle = one workspace: the device work of consecutive calls on DIFFERENT streams is ordered through
+  // this event (two batches in flight on one handle are serialised on the device, never corrupted)
+  hipEvent_t order_ev = nullptr;
+  hipStream_t order_st = nullptr;
+  bool order_set = false;
+  // host-pointer calls (gulon_index_batch_query) from several threads -- the reference's recall harness does
+  // that (Tests.scala:109-122) -- run concurrently on lazily created internal contexts, each with its own stream
+  std::mutex host_mu;
+  std::condition_variable host_cv;
+  std::vector<gulon_index *> host_all, host_free;   // internal contexts (owned); the handle itself is the first
+  bool host_self_busy = false;
+  hipStream_t host_stream = nullptr;
   hipEvent_t take_event() {
     if (ev_next == ev_pool.size()) {
       hipEvent_t e = nullptr;
@@ -73,10 +93,32 @@ struct gulon_index {
     return ev_pool[ev_next++];
   }
   ~gulon_index() {
+    for (auto *c : host_all) delete c;
     for (auto &e : ev_pool) (void)hipEventDestroy(e);
     if (fb_hint_h) (void)hipHostFree(fb_hint_h);
+    if (order_ev) (void)hipEventDestroy(order_ev);
+    if (host_stream) (void)hipStreamDestroy(host_stream);
   }
 };
+
+namespace gulon {
+// a new workspace over `parent`'s read-only data (no reference counting: the caller keeps `parent` alive)
+gulon_index *make_context(gulon_index *parent);
+// RAII: order this call's device work after the previous call's on the same handle when the stream differs
+struct StreamOrder {
+  gulon_index *ix;
+  hipStream_t st;
+  StreamOrder(gulon_index *ix_, hipStream_t st_) : ix(ix_), st(st_) {
+    if (!ix->order_ev) HIP_CHECK(hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming));
+    if (ix->order_set && ix->order_st != st) HIP_CHECK(hipStreamWaitEvent(st, ix->order_ev, 0));
+  }
+  void done() {
+    HIP_CHECK(hipEventRecord(ix->order_ev, st));
+    ix->order_st = st;
+    ix->order_set = true;
+  }
+};
+}  // namespace gulon
 
 
 namespace gulon {

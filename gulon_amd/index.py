@@ -55,10 +55,13 @@ def exact_nearest_neighbours(vectors, query, k, frm=0, until=None):
 class PQIndex:
     """PQIndex(productQuantizer, data) (Index.scala:385-441): owns the HBM copy of the codes."""
 
-    def __init__(self, product_quantizer: ProductQuantizer, data: EncodedMatrix, row_base=0):
+    def __init__(self, product_quantizer: ProductQuantizer, data: EncodedMatrix, row_base=0, _handle=None):
         self.product_quantizer = product_quantizer
         self.data = data
         self.row_base = row_base
+        if _handle is not None:
+            self._h = _handle
+            return
         h = C.c_void_p()
         packed = data.packed()
         N.check(N.lib().gulon_index_create(packed if packed.size else np.zeros(1, np.uint8), data.length,
@@ -66,6 +69,14 @@ class PQIndex:
                                            product_quantizer.num_clusters, product_quantizer.flat_centroids(),
                                            row_base, C.byref(h)))
         self._h = h
+
+    def context(self):
+        """Another workspace over the same device-resident codes and codebooks (gulon_index_context_create):
+        one per batch in flight / per querying thread; the codes live until the index and all its contexts
+        are closed."""
+        h = C.c_void_p()
+        N.check(N.lib().gulon_index_context_create(self._h, C.byref(h)))
+        return PQIndex(self.product_quantizer, self.data, self.row_base, _handle=h)
 
     @property
     def dimension(self):

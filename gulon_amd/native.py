@@ -23,6 +23,8 @@ ERR_OOM = -5
 FLAG_BOUNDARY_TIE = 1
 FLAG_INTERIOR_TIE = 2
 FLAG_EXACT_REPLAY = 4
+REPLAY_MAX_FLAGGED = 16
+REPLAY_POOL = 2048
 MAX_K = 63
 MAX_K_PEELED = 8191
 
@@ -79,6 +81,12 @@ SIGNATURES = {
     "gulon_prepare_query": (_i32, [_f32p, _i32, _i32, _i32, _f32p, _i32, _f32p]),
     "gulon_index_create": (_i32, [_u8p, _i32, _i32, _i32, _i32, _f32p, _i32, C.POINTER(_vp)]),
     "gulon_index_destroy": (_i32, [_vp]),
+    "gulon_index_context_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "gulon_sharded_index_create": (_i32, [_u8p, _i32, _i32, _i32, _i32, _f32p, _i32p, _i32, C.POINTER(_vp)]),
+    "gulon_sharded_index_destroy": (_i32, [_vp]),
+    "gulon_sharded_index_batch_query": (_i32, [_vp, _f32p, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
+    "gulon_sharded_index_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                                        C.POINTER(_i32)]),
     "gulon_index_batch_query": (_i32, [_vp, _f32p, _i32, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
     "gulon_index_batch_query_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_scan_partial_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -92,9 +100,9 @@ SIGNATURES = {
     "gulon_grouped_index_destroy": (_i32, [_vp]),
     "gulon_grouped_index_batch_query": (_i32, [_vp, _f32p, _i32, _i32, _i32, _i32, _i32p, _f32p, _i32p]),
     "gulon_grouped_index_batch_query_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "gulon_replay_pack_words": (C.c_int64, []),
-    "gulon_index_replay_collect_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "gulon_replay_apply_dev": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gulon_replay_pack_words": (C.c_int64, [_i32, _i32]),
+    "gulon_index_replay_collect_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "gulon_replay_apply_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_profile_read_ex": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "gulon_scan_tuning": (_i32, [C.c_char_p, _i32]),
     "gulon_topk_merge": (_i32, [_f32p, _i32p, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
@@ -118,7 +126,7 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gulon_abi_version() != 2:
+        if L.gulon_abi_version() != 3:
             raise ImportError("libgulon_hip.so ABI version mismatch")
         _lib = L
     return _lib

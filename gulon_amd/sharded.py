@@ -10,7 +10,10 @@ Index.scala:279) under the deterministic (distance, row id) order, so the
 result does not depend on the number of shards.
 
 Queries flagged with an exact distance tie are then replayed with the reference's heap
-semantics from the candidate rows of all shards (a second, fixed-size all-gather).
+semantics from the candidate rows of all shards: a fixed-size all-gather for the first 16 flagged
+queries, enqueued unconditionally, and -- only for batches with more of them (`complete()`) -- further
+rounds of 128 until every flagged query has been replayed, so that ids and order equal the unsharded
+index's whatever the number of shards and of ties.
 
 The compute engine is pluggable only so that the orchestration (bounds, row
 bases, gather layout) can be exercised on CPU with the gloo backend in tests;
@@ -41,7 +44,7 @@ def local_shard(pq: ProductQuantizer, encoded: EncodedMatrix, lo, hi) -> Encoded
 class HipEngine:
     """Local scan + merge on this rank's GPU through the C ABI (device-resident)."""
 
-    def __init__(self, pq, shard: EncodedMatrix, row_base, device):
+    def __init__(self, pq, shard: EncodedMatrix, row_base, device, parent=None):
         import torch
         from .index import PQIndex
         # torch's HIP runtime has to come up BEFORE libgulon_hip.so touches the device in this process
@@ -51,10 +54,17 @@ class HipEngine:
             torch.cuda.init()
         self.torch = torch
         self.device = device
-        self.index = PQIndex(pq, shard, row_base=row_base)
+        # parent: another HipEngine over the same shard -- this engine is then only a WORKSPACE (a query context,
+        # gulon_index_context_create) over that engine's codes: one per batch in flight, no second copy in HBM
+        self.index = PQIndex(pq, shard, row_base=row_base) if parent is None else parent.index.context()
         self.nloc = shard.length
-        # int32 words of one shard's candidate buffer for the exact replay of tie-flagged queries
-        self.replay_words = int(N.lib().gulon_replay_pack_words())
+        # flagged queries per round of the exact tie replay: the first, unconditional round is sized for the
+        # common case (a few ties per batch), later rounds (only when a batch needs them) take more at once
+        self.replay_first, self.replay_more, self.replay_pool = N.REPLAY_MAX_FLAGGED, 128, N.REPLAY_POOL
+
+    def replay_words(self, flagged):
+        """int32 words of one shard's candidate buffer for `flagged` tie-flagged queries."""
+        return int(N.lib().gulon_replay_pack_words(flagged, self.replay_pool))
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -96,14 +106,18 @@ class HipEngine:
         """(float32 view of the distance half, int32 row-id half) of a [2*B][K+1] int32 buffer."""
         return pk[:b].view(self.torch.float32), pk[b:]
 
-    def replay_collect(self, q, b, k, of, pack):
-        """This shard's candidate rows for the TopKHeap replay of the flagged queries."""
+    def replay_collect(self, q, b, k, of, pack, skip, flagged):
+        """This shard's candidate rows for the TopKHeap replay of flagged queries [skip, skip + flagged)."""
         N.check(N.lib().gulon_index_replay_collect_dev(self.index._h, q.data_ptr(), b, k, 0, self.nloc, of.data_ptr(),
-                                                       pack.data_ptr(), self._stream()))
+                                                       skip, flagged, self.replay_pool, pack.data_ptr(), self._stream()))
 
-    def replay_apply(self, packs, lists, b, k, oi, od, oc, of):
-        N.check(N.lib().gulon_replay_apply_dev(packs.data_ptr(), lists, b, k, oi.data_ptr(), od.data_ptr(),
-                                               oc.data_ptr(), of.data_ptr(), self._stream()))
+    def replay_apply(self, packs, lists, b, k, oi, od, oc, of, flagged):
+        N.check(N.lib().gulon_replay_apply_dev(packs.data_ptr(), lists, flagged, self.replay_pool, b, k, oi.data_ptr(),
+                                               od.data_ptr(), oc.data_ptr(), of.data_ptr(), self._stream()))
+
+    def replay_total(self, pack):
+        """Flagged queries of the whole batch (word 3 of a collected pack); waits for the pack."""
+        return int(pack[3].item())
 
 
 class ShardedIndex:
@@ -143,8 +157,8 @@ class ShardedIndex:
             if self.share_bounds:
                 self._bufs[key]["bd"] = e.alloc((b, k + 1), "f32")
                 self._bufs[key]["abd"] = e.alloc((self.world * b, k + 1), "f32")
-            words = getattr(e, "replay_words", 0)
-            if words and self.collective:
+            if hasattr(e, "replay_words") and self.collective:
+                words = e.replay_words(e.replay_first)
                 self._bufs[key]["rp"] = e.alloc((words,), "i32")
                 self._bufs[key]["arp"] = e.alloc((self.world * words,), "i32")
         return self._bufs[key]
@@ -175,17 +189,47 @@ class ShardedIndex:
             self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
             if "rp" in u:
                 # queries with exact distance ties: every shard contributes the rows that may insert into
-                # the reference's heap, the union is replayed identically on every rank (TopKHeap.scala:57-79)
-                self.engine.replay_collect(q, b, k, u["of"], u["rp"])
+                # the reference's heap, the union is replayed identically on every rank (TopKHeap.scala:57-79).
+                # This first round (replay_first queries) is unconditional -- no host synchronisation;
+                # complete() looks at the batch's flag count afterwards and runs further rounds if needed.
+                e = self.engine
+                e.replay_collect(q, b, k, u["of"], u["rp"], 0, e.replay_first)
                 self._all_gather(u["arp"], u["rp"])
-                self.engine.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
+                e.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"], e.replay_first)
+                self._pending = (q, b, k)
         return u["oi"], u["od"], u["oc"], u["of"]
+
+    def complete(self):
+        """Finish the batch enqueued last: when more queries were tie-flagged than the first replay round
+        holds, run further rounds (collect -> all-gather -> literal TopKHeap) until every flagged query has
+        been replayed.  Waits for the batch (reads its flag count); every rank sees the same count, so all
+        ranks run the same number of rounds.  Returns the number of extra rounds."""
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is None:
+            return 0
+        q, b, k = pend
+        u, e = self._buffers(b, k), self.engine
+        total, skip, rounds = e.replay_total(u["rp"]), e.replay_first, 0
+        self.last_flagged = total
+        if total > skip:
+            words = e.replay_words(e.replay_more)
+            if "rp2" not in u:
+                u["rp2"] = e.alloc((words,), "i32")
+                u["arp2"] = e.alloc((self.world * words,), "i32")
+            while skip < total:
+                e.replay_collect(q, b, k, u["of"], u["rp2"], skip, e.replay_more)
+                self._all_gather(u["arp2"], u["rp2"])
+                e.replay_apply(u["arp2"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"], e.replay_more)
+                skip += e.replay_more
+                rounds += 1
+        return rounds
 
     def batch_query(self, k, queries):
         """Host convenience: numpy in, numpy out (idx [B][K], dist, count, flags)."""
         q = N.f32(queries)
         b = q.shape[0]
         oi, od, oc, of = self.batch_query_dev(self.engine.to_device(q), b, k)
+        self.complete()
         return tuple(t.cpu().numpy() for t in (oi, od, oc, of))
 
 
@@ -247,3 +291,57 @@ def build_sharded(dm, num_clusters, num_quantizers, max_iterations, rank=0, worl
     full = EncodedMatrix(coder, encs)
     lo, hi = shard_bounds(n, world, rank)
     return pq, local_shard(pq, full, lo, hi), lo, hi
+
+
+# ---------------------------------------------------------------------------------------
+# One process, several GPUs: the C ABI's own sharded index (what a JVM binds).
+# ---------------------------------------------------------------------------------------
+class NodeShardedIndex:
+    """PQIndex row-sharded over the GPUs of this node inside ONE process (gulon_sharded_index_*,
+    sharded.hip): shard s holds rows [n*s/S, n*(s+1)/S) on devices[s]; bounds, partial lists and
+    tie-replay candidates travel between the devices by RCCL all-gathers issued from this process.
+    Results equal PQIndex.batch_query bit for bit (Index.scala:417-440, TopKHeap.scala:44-79)."""
+
+    def __init__(self, product_quantizer: ProductQuantizer, data: EncodedMatrix, devices):
+        self.product_quantizer, self.data = product_quantizer, data
+        dev = N.i32(list(devices))
+        h = C.c_void_p()
+        packed = data.packed()
+        N.check(N.lib().gulon_sharded_index_create(packed if packed.size else np.zeros(1, np.uint8), data.length,
+                                                   product_quantizer.dimension, len(product_quantizer.quantizers),
+                                                   product_quantizer.num_clusters, product_quantizer.flat_centroids(),
+                                                   dev, len(dev), C.byref(h)))
+        self._h = h
+
+    def info(self):
+        v = [C.c_int32(0) for _ in range(5)]
+        N.check(N.lib().gulon_sharded_index_info(self._h, *[C.byref(x) for x in v]))
+        return dict(shards=v[0].value, devices=v[1].value, rccl_version=v[2].value, last_replay_rounds=v[3].value,
+                    last_flagged_queries=v[4].value)
+
+    def batch_query_raw(self, k, vectors):
+        q = N.f32(vectors).reshape(-1, self.product_quantizer.dimension)
+        b = q.shape[0]
+        oi = np.zeros((b, max(k, 1)), np.int32)
+        od = np.zeros((b, max(k, 1)), np.float32)
+        oc = np.zeros(max(b, 1), np.int32)
+        of = np.zeros(max(b, 1), np.int32)
+        N.check(N.lib().gulon_sharded_index_batch_query(self._h, q.reshape(-1) if b else np.zeros(1, np.float32), b, k,
+                                                        oi.reshape(-1), od.reshape(-1), oc, of))
+        return oi[:, :k], od[:, :k], oc[:b], of[:b]
+
+    def batch_query(self, k, vectors):
+        from .index import Result
+        oi, od, oc, of = self.batch_query_raw(k, vectors)
+        return [Result(oi[i, :oc[i]].copy(), od[i, :oc[i]].copy(), int(of[i])) for i in range(len(oc))]
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            N.lib().gulon_sharded_index_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

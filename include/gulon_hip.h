@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GULON_ABI_VERSION 2
+#define GULON_ABI_VERSION 3
 
 #define GULON_OK 0
 #define GULON_ERR_INVALID_ARGUMENT (-1) /* reference: require(...) / IllegalArgumentException */
@@ -56,6 +56,7 @@ extern "C" {
 
 typedef struct gulon_dataset gulon_dataset; /* device-resident Matrix            */
 typedef struct gulon_index gulon_index;     /* device-resident PQIndex (codes+PQ) */
+typedef struct gulon_sharded_index gulon_sharded_index; /* PQIndex row-sharded over the GPUs of one node */
 
 /* One KMeans.ProgressReport (KMeans.scala:119-127) as plain numbers. */
 typedef struct {
@@ -167,6 +168,22 @@ int32_t gulon_prepare_query(const float *cents, int32_t d, int32_t m, int32_t k,
 int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
                            const float *cents, int32_t row_base, gulon_index **out);
 int32_t gulon_index_destroy(gulon_index *idx);
+/* Concurrency rules of a gulon_index handle (the reference's PQIndex is immutable and queried from many
+ * threads at once, Tests.scala:109-122):
+ *  - one handle = one workspace.  All per-query scratch (tables, partial lists, survivor queues, replay pools)
+ *    belongs to the handle.  Calls on one handle may come from any thread and any stream: the host side is
+ *    serialised by a mutex, and the DEVICE work of a call on another stream than the previous call's is
+ *    ordered behind it with an event -- two batches "in flight" on one handle run one after the other,
+ *    never on top of each other's scratch.
+ *  - gulon_index_context_create gives another workspace over the SAME read-only codes and codebooks (no
+ *    copy): one context per batch in flight (bench.py: one per stream) overlaps their device work.  A
+ *    context is destroyed with gulon_index_destroy; the codes live until the index and all of its contexts
+ *    are destroyed.  Create and use a context with the index's device current.
+ *  - the host-pointer gulon_index_batch_query takes such a context internally (up to GULON_HOST_CONTEXTS,
+ *    default 4, created on first use, each with a stream of its own), so concurrent callers overlap.
+ *  - the two-call sequence scan_bounds -> scan_partial_bounded must not be interleaved with other calls on the
+ *    same handle (any other query call drops the pending first half: GULON_ERR_INVALID_ARGUMENT). */
+int32_t gulon_index_context_create(gulon_index *parent, gulon_index **out);
 /* PQIndex.batchQuery(k, vectors, from, until) (Index.scala:417-440) followed by
  * Index.Result.fromHeap (Index.scala:83-94): per query the K nearest rows of
  * [from, until) by ADC distance, ascending.  out_idx/out_dist: [B][K];
@@ -207,22 +224,47 @@ int32_t gulon_index_scan_partial_bounded_dev(gulon_index *idx, const float *d_qu
                                              void *stream);
 /* Exact TopKHeap replay of tie-flagged queries across ROW SHARDS (the unsharded
  * gulon_index_batch_query* does this internally).  After gulon_topk_merge_dev every shard holds
- * the same flags; each shard then collects, for the first GULON_REPLAY_MAX_FLAGGED flagged
- * queries, the rows of its range that may insert into the reference's heap (a superset, with
- * global row ids) into a fixed-size buffer of gulon_replay_pack_words() int32 words; the
- * buffers of all shards (in row order: shard 0 first), laid out back to back, go to
- * gulon_replay_apply_dev, which runs the literal TopKHeap (TopKHeap.scala:57-79) over their
- * union and overwrites idx/dist/count of those queries, setting GULON_FLAG_EXACT_REPLAY.
- * Further flagged queries, or one with more than GULON_REPLAY_POOL candidates in a shard, keep
- * the (distance, row id) result and their tie flags. */
+ * the same flags; each shard then collects, for up to `max_flagged` flagged queries after the first
+ * `skip` ones (ascending query number), the rows of its range that may insert into the reference's
+ * heap (a superset, with global row ids, at most `pool` per query) into a buffer of
+ * gulon_replay_pack_words(max_flagged, pool) int32 words; word [3] of the buffer receives the number
+ * of flagged queries of the whole batch.  The buffers of all shards (in row order: shard 0 first),
+ * laid out back to back, go to gulon_replay_apply_dev, which runs the literal TopKHeap
+ * (TopKHeap.scala:57-79) over their union and overwrites idx/dist/count of those queries, setting
+ * GULON_FLAG_EXACT_REPLAY.  A batch with more flagged queries than one round holds is finished by
+ * further rounds with skip advanced (gulon_sharded_index_batch_query and gulon_amd/sharded.py loop
+ * until skip >= word [3]).  A query with more than `pool` candidates in a shard (or more than 16 384
+ * over all shards) keeps the (distance, row id) result and its tie flags.
+ * max_flagged in [1, 1024], pool in [64, 8192]; the defaults below size the first, unconditional round. */
 #define GULON_REPLAY_MAX_FLAGGED 16
 #define GULON_REPLAY_POOL 2048
-int64_t gulon_replay_pack_words(void);
+int64_t gulon_replay_pack_words(int32_t max_flagged, int32_t pool); /* -1: out of range */
 int32_t gulon_index_replay_collect_dev(gulon_index *idx, const float *d_queries, int32_t b, int32_t k_nn,
-                                       int32_t from, int32_t until, const int32_t *d_flags, int32_t *d_pack,
-                                       void *stream);
-int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t b, int32_t k_nn, int32_t *d_out_idx,
-                               float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+                                       int32_t from, int32_t until, const int32_t *d_flags, int32_t skip,
+                                       int32_t max_flagged, int32_t pool, int32_t *d_pack, void *stream);
+int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t max_flagged, int32_t pool, int32_t b,
+                               int32_t k_nn, int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count,
+                               int32_t *d_out_flags, void *stream);
+/* ---- PQIndex row-sharded over the GPUs of one node, ONE host process (sharded.hip) ---------------
+ * The multi-GPU form of PQIndex.batchQuery for a caller that is one process (the JVM): shard s holds rows
+ * [n*s/S, n*(s+1)/S) -- the from/until contract of Index.scala:417-419 -- on device devices[s] (a device
+ * may hold several shards); every query batch runs bounds -> scan -> merge -> tie replay on all shards
+ * with three RCCL all-gathers over xGMI in between (ncclCommInitAll over the distinct devices; librccl is
+ * loaded on first use).  The merge is TopKHeap.merge (TopKHeap.scala:44-53) under the (distance, row id)
+ * order and tie-flagged queries are replayed with the literal heap over the candidates of all shards, in
+ * as many rounds as the batch needs: ids, order, distances and flags equal the unsharded
+ * gulon_index_batch_query bit for bit, whatever the number of shards.  codes/cents as gulon_index_create
+ * (all n rows); k_nn <= GULON_MAX_K. */
+int32_t gulon_sharded_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
+                                   const float *cents, const int32_t *devices, int32_t n_shards,
+                                   gulon_sharded_index **out);
+int32_t gulon_sharded_index_destroy(gulon_sharded_index *idx);
+int32_t gulon_sharded_index_batch_query(gulon_sharded_index *idx, const float *queries, int32_t b, int32_t k_nn,
+                                        int32_t *out_idx, float *out_dist, int32_t *out_count, int32_t *out_flags);
+/* shards, distinct devices (= RCCL ranks), ncclGetVersion, and of the last batch: replay rounds, flagged queries
+ * (every out pointer nullable) */
+int32_t gulon_sharded_index_info(const gulon_sharded_index *idx, int32_t *n_shards, int32_t *n_devices,
+                                 int32_t *rccl_version, int32_t *last_replay_rounds, int32_t *last_flagged_queries);
 /* ---- GroupedIndex (Index.scala:231-308): coarse groups + product-quantized residuals ---------
  * Rows are in GROUPED order (WordVectors.grouped, WordVectors.scala:24-58): stably ordered by the
  * coarse cluster they were assigned to; group c covers rows [offsets[c-1], offsets[c]) (first group

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     extra = sorted(s for s in exported if s.startswith("gulon_") and s not in _header_symbols())
     assert not extra, extra
     L = native.lib()
-    assert L.gulon_abi_version() == 2
+    assert L.gulon_abi_version() == 3
 
 
 def test_host_only_entry_points_match_oracle(oracle):

@@ -145,6 +145,22 @@ def test_shared_bounds_with_ties_replayed(oracle, g, tune):
     assert ((res[3] & 3) != 0).any() and (((res[3] & 3) != 0) == ((res[3] & 4) != 0)).all()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_every_query_flagged_across_shards_is_replayed(oracle, g, tune, world):
+    """150 queries that all tie across the first and the last shard: the first replay round takes 16, further
+    rounds (ShardedIndex.complete) the rest -- ids and order equal the unsharded index's and the oracle's."""
+    n, d, m, k, B, K = 200000, 32, 8, 16, 150, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=19, dup=40000)
+    whole = g.PQIndex(pq, enc)
+    Q = np.stack([whole.decode(r) for r in range(0, 40000, 40000 // B)][:B]).astype(np.float32)
+    full = whole.batch_query_raw(K, Q)
+    res = sharded_query(g, pq, enc, n, world, Q, K)
+    _same(res, full)
+    assert ((res[3] & 3) != 0).all() and ((res[3] & 4) != 0).all()
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    assert np.array_equal(res[0], oi) and np.array_equal(bits(res[1]), bits(od))
+
+
 @pytest.mark.parametrize("B,K", [(1, 1), (5, 63), (130, 2)])
 def test_shared_bounds_ragged_batches(g, tune, B, K):
     n, d, m, k = 300000, 32, 8, 256

@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 INT_MAX = 2 ** 31 - 1
 
 
-FLAGGED = 4     # flagged queries the test double replays per batch
+FLAGGED = 4     # flagged queries the test double replays in the first round
+MORE = 6        # ... and in every further round (ShardedIndex.complete)
 
 
 class OracleEngine:
@@ -22,8 +23,11 @@ class OracleEngine:
         self.o, self.idx, self.d, self.k, self.cents, self.row_base = oracle, idx_local, d, k, cents, row_base
         self.nloc = idx_local.shape[1]
         self.cap = cap or self.nloc          # rows of the largest shard: every rank's buffer has the same size
-        # candidate buffer: [nflag][rows here][FLAGGED qids][FLAGGED x cap distance bits][FLAGGED x cap row ids]
-        self.replay_words = 2 + FLAGGED + 2 * FLAGGED * self.cap
+        self.replay_first, self.replay_more = FLAGGED, MORE
+
+    def replay_words(self, F):
+        # candidate buffer: [nflag here][rows here][flagged in the batch][F qids][F x cap distance bits][F x cap row ids]
+        return 3 + F + 2 * F * self.cap
 
     def alloc(self, shape, dtype):
         return torch.empty(shape, dtype={"f32": torch.float32, "i32": torch.int32}[dtype])
@@ -63,38 +67,42 @@ class OracleEngine:
                 od[r, e] = v
                 oi[r, e] = i
 
-    def replay_collect(self, q, b, k, of, pack):
+    def replay_collect(self, q, b, k, of, pack, skip, F):
         """Every local row is a candidate (a superset of the inserting rows), with its exact distance."""
-        flagged = [r for r in range(b) if int(of[r]) & 3][:FLAGGED]
-        w = np.zeros(self.replay_words, np.int32)
-        w[0], w[1] = len(flagged), self.nloc
-        w[2:2 + FLAGGED] = -1
+        every = [r for r in range(b) if int(of[r]) & 3]
+        flagged = every[skip:skip + F]
+        w = np.zeros(self.replay_words(F), np.int32)
+        w[0], w[1], w[2] = len(flagged), self.nloc, len(every)
+        w[3:3 + F] = -1
         T = self.o.prepare_query(self.cents, self.d, self.idx.shape[0], self.k, q.numpy())
         m, n = self.idx.shape
         for f, r in enumerate(flagged):
-            w[2 + f] = r
+            w[3 + f] = r
             acc = np.zeros(n, np.float32)
             for j in range(m):                                    # the reference's order: j ascending, fp32
                 acc = (acc + T[r, j, self.idx[j]]).astype(np.float32)
-            o = 2 + FLAGGED + f * self.cap
+            o = 3 + F + f * self.cap
             w[o:o + n] = acc.view(np.int32)
-            o2 = 2 + FLAGGED + FLAGGED * self.cap + f * self.cap
+            o2 = 3 + F + F * self.cap + f * self.cap
             w[o2:o2 + n] = np.arange(n, dtype=np.int32) + self.row_base
         pack.copy_(torch.from_numpy(w))
 
-    def replay_apply(self, packs, lists, b, k, oi, od, oc, of):
+    def replay_total(self, pack):
+        return int(pack[2])
+
+    def replay_apply(self, packs, lists, b, k, oi, od, oc, of, F):
         """Literal TopKHeap over the union of the shards' candidates, in row order."""
         w = packs.numpy()
         per = len(w) // lists
         nflag = int(w[0])
         for f in range(nflag):
-            r = int(w[2 + f])
+            r = int(w[3 + f])
             rows, dists = [], []
             for l in range(lists):
                 wl = w[l * per:(l + 1) * per]
                 n = int(wl[1])
-                o = 2 + FLAGGED + f * self.cap
-                o2 = 2 + FLAGGED + FLAGGED * self.cap + f * self.cap
+                o = 3 + F + f * self.cap
+                o2 = 3 + F + F * self.cap + f * self.cap
                 rows.append(wl[o2:o2 + n])
                 dists.append(wl[o:o + n].view(np.float32))
             rows, dists = np.concatenate(rows), np.concatenate(dists)
@@ -146,7 +154,7 @@ class BoundedOracleEngine(OracleEngine):
         pi.copy_(torch.from_numpy(i))
 
 
-def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0, bounded=False):
+def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0, bounded=False, flagged_min=0, dup_queries=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -160,6 +168,11 @@ def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0, bounded=False):
     if dup:
         idx[:, -dup:] = idx[:, :dup]          # identical codes in the first and the last shard: distance ties
     Q = rng.standard_normal((B, d)).astype(np.float32)
+    if dup_queries:                           # every query sits exactly on a duplicated row: all of them tie
+        fr, un = oracle.subvectors(d, m)
+        for r in range(B):
+            for j in range(m):
+                Q[r, fr[j]:un[j]] = cents[k * fr[j] + idx[j, r] * (un[j] - fr[j]): k * fr[j] + (idx[j, r] + 1) * (un[j] - fr[j])]
     lo, hi = shard_bounds(n, world, rank)
     eng = (BoundedOracleEngine if bounded else OracleEngine)(oracle, np.ascontiguousarray(idx[:, lo:hi]), d, k, cents, lo,
                                                              cap=-(-n // world))
@@ -171,8 +184,10 @@ def _worker(rank, world, port, n, d, m, k, B, K, out, dup=0, bounded=False):
     for r in range(B):      # ids: the reference's wherever there is no tie or the tie was replayed
         if of[r] == 0 or (of[r] & 4):
             ok = ok and bool(np.array_equal(oi[r], ei[r]))
-    if dup:
-        ok = ok and bool(((of & 3) != 0).any()) and bool(((of & 4) != 0).any())
+    if dup:     # ties exist, and EVERY flagged query was replayed (more of them than one round holds: complete())
+        ok = ok and bool(((of & 3) != 0).any()) and bool((((of & 3) != 0) == ((of & 4) != 0)).all())
+        if flagged_min:
+            ok = ok and int(((of & 3) != 0).sum()) >= flagged_min and sh.last_flagged >= flagged_min
     t = torch.tensor([1 if ok else 0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -226,6 +241,24 @@ def test_sharded_tie_replay_equals_reference_heap():
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, 8, 2, 4, 3, 5, out, 250)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1
+
+
+@pytest.mark.parametrize("world,bounded", [(2, False), (3, True)])
+def test_sharded_tie_replay_more_flagged_than_one_round(world, bounded):
+    """17 queries that all tie across shards, 4 per first round and 6 per further round in the test double:
+    ShardedIndex.complete() must keep exchanging candidates until every flagged query has been replayed."""
+    n, B = 600, 17
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 8, 2, 4, B, 5, out, 250, bounded, B, True))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
