@@ -840,6 +840,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   launch_merge(final_out, ix->fin_v.p, ix->fin_i.p, 1, 0LL, (long long)keff, B, K, d_oi, d_od, d_oc, flags, d_pv, d_pi,
                st);
   if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
+  if (final_out && replay_enabled()) run_nonfinite_literal(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, d_of, st);
 }
 
 }  // namespace gulon

@@ -813,6 +813,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
                d_od, d_oc, flags, d_pv, d_pi, st);
   // queries with exact distance ties: replay the reference heap's insertion history
   if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
+  // queries whose distances can be NaN / +inf: the literal heap over all rows (TopKHeap.scala:69-79)
+  if (final_out && replay_enabled()) run_nonfinite_literal(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, d_of, st);
 }
 
 }  // namespace
@@ -870,6 +872,7 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
     ix->from.upload(from.data(), m);
     ix->sdim.upload(sdim.data(), m);
     ix->cents.upload(cents, (size_t)k * d);
+    ix->cents_absmax = centroid_absmax(ix->cents.p, (long long)k * d);
 
     int bytes_per_code = 0;
     gulon_coder_bytes(width, n, &bytes_per_code);
@@ -916,6 +919,7 @@ gulon_index *make_context(gulon_index *parent) {
   c->n = parent->n; c->d = parent->d; c->m = parent->m; c->k = parent->k; c->row_base = parent->row_base;
   c->vec = parent->vec; c->ng = parent->ng; c->m_pad = parent->m_pad; c->nsub = parent->nsub; c->w = parent->w;
   c->wide = parent->wide;
+  c->cents_absmax = parent->cents_absmax;
   c->codes.borrow(parent->codes);
   c->wcodes.borrow(parent->wcodes);
   c->cents.borrow(parent->cents);

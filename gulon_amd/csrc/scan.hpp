@@ -54,6 +54,8 @@ struct gulon_index {
   DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
   DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;
   DevBuf<uint8_t> qtab;             // [Bq/16][m_pad][256][16] quantized table entries
+  DevBuf<float> nf_tables;          // literal.hip: one fp32 table per workgroup of the non-finite pass
+  float cents_absmax = 0.f;         // max |centroid coordinate| (+inf if any is NaN / inf): overflow bound of a query
   // optional hipEvent bracketing of the dominant scan kernel (bench.py roofline line)
   bool profile = false;
   long long prof_rows = 0;          // rows covered by the bracketed launches
@@ -196,6 +198,10 @@ __device__ inline uint32_t code_byte<16>(const uint4 &w, int b) {
 // Index.prepareQuery tables, W queries interleaved (scan.hip)
 void launch_build_tables(int W, gulon_index *ix, const float *dQ, int B, int Bpad, float *tables, hipStream_t st,
                          const int *live_queries = nullptr, float *mins = nullptr);
+// literal.hip: queries whose distances can be NaN / +inf are redone through the literal TopKHeap over all rows
+float centroid_absmax(const float *d_cents, long long count);
+void run_nonfinite_literal(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
+                           int *d_oc, int *d_of, hipStream_t st);
 // For every query flagged with an exact distance tie, recompute the result with the
 // reference's TopKHeap semantics (insertion history in row order) -- replay.hip
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,

@@ -344,6 +344,10 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
       skip += F;
       if (skip >= flagged) break;
     }
+    for (auto &dv : sx->devs) {   // all-NaN queries: the reference's first-K-rows answer (TopKHeap.scala:69-79)
+      HIP_CHECK(hipSetDevice(dv.device));
+      status(gulon_nan_queries_fix_dev(dv.q.p, b, sx->d, K, sx->n, dv.oi.p, dv.od.p, dv.oc.p, dv.of.p, dv.st));
+    }
     sx->last_rounds = rounds;
     sx->last_flagged = flagged;
     Dev &d0 = sx->devs[0];

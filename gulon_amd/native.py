@@ -23,6 +23,7 @@ ERR_OOM = -5
 FLAG_BOUNDARY_TIE = 1
 FLAG_INTERIOR_TIE = 2
 FLAG_EXACT_REPLAY = 4
+FLAG_NONFINITE = 8
 REPLAY_MAX_FLAGGED = 16
 REPLAY_POOL = 2048
 MAX_K = 63
@@ -105,6 +106,7 @@ SIGNATURES = {
     "gulon_replay_apply_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_profile_read_ex": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "gulon_scan_tuning": (_i32, [C.c_char_p, _i32]),
+    "gulon_nan_queries_fix_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_topk_merge": (_i32, [_f32p, _i32p, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
     "gulon_exact_knn": (_i32, [_vp, _i32, _i32, _f32p, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
     "gulon_distance_sq_rows": (_i32, [_vp, _f32p, _i32, _i32p, _i32, _f32p]),

@@ -119,6 +119,11 @@ class HipEngine:
         """Flagged queries of the whole batch (word 3 of a collected pack); waits for the pack."""
         return int(pack[3].item())
 
+    def nan_fix(self, q, b, k, n_total, oi, od, oc, of):
+        """All-NaN queries: the reference's first-K-rows answer (gulon_nan_queries_fix_dev)."""
+        N.check(N.lib().gulon_nan_queries_fix_dev(q.data_ptr(), b, q.shape[1], k, n_total, oi.data_ptr(), od.data_ptr(),
+                                                  oc.data_ptr(), of.data_ptr(), self._stream()))
+
 
 class ShardedIndex:
     """One rank's view of the row-sharded flat index."""
@@ -197,6 +202,8 @@ class ShardedIndex:
                 self._all_gather(u["arp"], u["rp"])
                 e.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"], e.replay_first)
                 self._pending = (q, b, k)
+            if hasattr(self.engine, "nan_fix"):
+                self.engine.nan_fix(q, b, k, self.n_total, u["oi"], u["od"], u["oc"], u["of"])
         return u["oi"], u["od"], u["oc"], u["of"]
 
     def complete(self):

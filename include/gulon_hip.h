@@ -49,6 +49,9 @@ extern "C" {
 #define GULON_FLAG_EXACT_REPLAY 4 /* tie resolved by replaying the reference heap's insertion history:
                                      ids and order are exactly TopKHeap's (single, unsharded index only) */
 
+#define GULON_FLAG_NONFINITE 8    /* the query's distances can be NaN / +inf (NaN or huge query components, NaN
+                                     centroids): result = the literal TopKHeap over all rows, TopKHeap.scala:69-79 */
+
 #define GULON_MAX_K 63 /* neighbours per query held by one wavefront list: fast path, exact tie replay,
                           sharded merge */
 #define GULON_MAX_K_PEELED 8191 /* larger k_nn (unsharded queries, exact kNN): the result is peeled 64
@@ -315,6 +318,14 @@ int32_t gulon_scan_tuning(const char *key, int32_t value);
 int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists,
                              int64_t list_stride, int32_t b, int32_t k_nn, int32_t *d_out_idx,
                              float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);
+/* All-NaN queries on a ROW-SHARDED index: a query with a NaN component has every distance NaN
+ * (Index.scala:352-383), the reference's heap then keeps the first min(K, n_total) rows it is offered
+ * (TopKHeap.scala:69-79) and Result.fromHeap returns them as [1, ..., c-1, 0] with NaN distances.  Run on the
+ * merged result of the shards (gulon_amd/sharded.py, gulon_sharded_index_batch_query); the unsharded
+ * gulon_index_batch_query* handles every non-finite case itself (GULON_FLAG_NONFINITE). */
+int32_t gulon_nan_queries_fix_dev(const float *d_queries, int32_t b, int32_t d, int32_t k_nn, int32_t n_total,
+                                  int32_t *d_out_idx, float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags,
+                                  void *stream);
 /* host-pointer convenience form of the same merge */
 int32_t gulon_topk_merge(const float *part_dist, const int32_t *part_idx, int32_t lists, int32_t b,
                          int32_t k_nn, int32_t *out_idx, float *out_dist, int32_t *out_count,

@@ -166,6 +166,25 @@ def test_c_abi_sharded_index_every_query_tied(oracle, g, devices):
     sx.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_c_abi_sharded_index_nan_and_inf_queries(oracle, g, devices):
+    """A NaN query component makes every distance NaN: the reference returns the first K rows of the index as
+    [1, ..., K-1, 0] (TopKHeap.scala:69-79) -- also across shards; +inf distances go through the tie replay."""
+    from gulon_amd.sharded import NodeShardedIndex
+    n, d, m, k, K, B = 100000, 32, 8, 256, 10, 5
+    cents, idx, pq, enc = _make(g, n, d, m, k, seed=31)
+    Q = np.random.default_rng(3).standard_normal((B, d)).astype(np.float32)
+    Q[1, 7] = np.nan
+    Q[3, :] = 1e30
+    sx = NodeShardedIndex(pq, enc, devices)
+    ri, rd, rc, rf = sx.batch_query_raw(K, Q)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    assert np.array_equal(rc, oc) and np.array_equal(ri, oi)
+    assert np.array_equal(np.isnan(rd), np.isnan(od)) and np.array_equal(bits(rd[~np.isnan(od)]), bits(od[~np.isnan(od)]))
+    assert rf[1] & 8
+    sx.close()
+
+
 def test_c_abi_sharded_index_argument_errors(g):
     from gulon_amd.sharded import NodeShardedIndex
     cents, idx, pq, enc = _make(g, 1000, 8, 2, 16, seed=1)

@@ -151,19 +151,54 @@ def test_queue_overflow_falls_back_to_exact_scan(oracle, g, tune):
     ix.close()
 
 
-def test_nan_and_huge_queries(oracle, g, tune):
-    n, d, m, k, B, K = 30000, 64, 16, 256, 6, 10
+def _check_nonfinite(res, oi, od, oc):
+    """ids and order equal the oracle's for every query; distances bit for bit, NaNs as NaNs."""
+    for q, r in enumerate(res):
+        assert len(r) == oc[q]
+        assert r.rows.tolist() == oi[q, :oc[q]].tolist(), q
+        e = od[q, :oc[q]]
+        assert np.array_equal(np.isnan(r.distances), np.isnan(e))
+        ok = ~np.isnan(e)
+        assert np.array_equal(bits(r.distances[ok]), bits(e[ok]))
+
+
+@pytest.mark.parametrize("n,frm,until", [(30000, 0, None), (90000, 0, None), (90000, 1234, 80001), (300, 10, 15)])
+def test_nan_and_huge_queries(oracle, g, tune, n, frm, until):
+    """TopKHeap.update inserts a NaN while the heap is not full and nothing afterwards (TopKHeap.scala:69-79): a
+    query with a NaN component gets the first K rows of the range, drained as [1, ..., K-1, 0]; a query whose
+    distances all overflow to +inf likewise.  Compared with the oracle, query by query."""
+    d, m, k, B, K = 64, 16, 256, 6, 10
     cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=13)
     Q = np.random.default_rng(5).standard_normal((B, d)).astype(np.float32)
-    Q[1, 3] = np.nan            # every distance NaN: nothing is returned
+    Q[1, 3] = np.nan            # every distance NaN
     Q[4, :] = 1e30              # every distance overflows to +inf
+    Q[5, 60] = np.inf           # inf - c = inf, squared inf: every distance +inf
+    ix = g.PQIndex(pq, enc)
+    until = n if until is None else until
+    res = ix.batch_query(K, Q, frm, until)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, until)
+    _check_nonfinite(res, oi, od, oc)
+    assert res[1].flags & 8 and res[4].flags & 8 and not (res[0].flags & 8)
+    assert np.isnan(res[1].distances).all() and res[1].rows.tolist() == [frm + (e + 1) % len(res[1]) for e in range(len(res[1]))]
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [5000, 70000])
+def test_nan_centroids_mixed_distances(oracle, g, tune, n):
+    """NaN / inf codebook entries: some rows have NaN distances, the others ordinary ones -- the heap is no longer
+    a heap once a NaN sits in it, and the result is whatever the reference's update sequence leaves."""
+    d, m, k, B, K = 16, 4, 16, 7, 6
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=21)
+    cents = cents.copy()
+    cents[5] = np.nan                       # quantizer 0, centroid 1
+    cents[k * 8 + 3 * 4 + 2] = np.inf       # quantizer 2 (from = 8, s = 4), centroid 3
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    Q = np.random.default_rng(8).standard_normal((B, d)).astype(np.float32)
     ix = g.PQIndex(pq, enc)
     res = ix.batch_query(K, Q)
     oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
-    for q in (0, 2, 3, 5):
-        assert res[q].rows.tolist() == oi[q, :oc[q]].tolist()
-        assert np.array_equal(bits(res[q].distances), bits(od[q, :oc[q]]))
-    assert len(res[1]) == 0
+    _check_nonfinite(res, oi, od, oc)
+    assert all(r.flags & 8 for r in res)
     ix.close()
 
 
