@@ -33,7 +33,8 @@ struct gulon_grouped_index {
   DevBuf<uint16_t> codes2;         // [n/64][ceil(m/2)][64]: the codes of quantizers 2h (low byte) and 2h+1 (gq_scan_qm)
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
-  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok, nn_sized;
+  DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok, nn_sized, lit_flag;
+  int n_empty = 0;                 // groups without rows (the reference's leading empty group, WordVectors.scala:38-39)
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
 };
@@ -142,14 +143,18 @@ __global__ __launch_bounds__(64) void gq_nearest_groups(const float *__restrict_
 __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict__ cdist, int g, int n2,
                                                         const int *__restrict__ bounds, int by_vectors, int limit,
                                                         int *__restrict__ nn, int stride, int *__restrict__ nn_cnt,
-                                                        const int *__restrict__ done) {
+                                                        const int *__restrict__ done, int *__restrict__ lit) {
   extern __shared__ float gs_lds[];
   if (done && done[blockIdx.x]) return;   // gq_select_groups already answered this query
   float *sv = gs_lds;
   int *si = reinterpret_cast<int *>(gs_lds + n2);
+  __shared__ int s_lit;
   const int q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_lit = 0;
+  __syncthreads();
   for (int e = tid; e < n2; e += 256) {
     float v = e < g ? cdist[(size_t)q * g + e] : INFINITY;
+    if (v != v) s_lit = 1;            // a NaN distance: only the literal heap knows what the reference does with it
     sv[e] = v != v ? INFINITY : v;    // NaN distances order last
     si[e] = e < g ? e : INT_MAX;
   }
@@ -180,6 +185,13 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
   __syncthreads();
   const int cnt = nn_cnt[q];
   for (int e = tid; e < cnt; e += 256) nn[(size_t)q * stride + e] = si[e];
+  // (distance, id) order is the reference's heap order only while the entries that decide the answer -- the
+  // searched ones and the first one left out -- have pairwise different distances; otherwise gq_literal_groups
+  // redoes this query (equal centroid distances are common: the reference's leading empty group repeats a centroid)
+  for (int e = tid; e + 1 < min(cnt + 1, g); e += 256)
+    if (sv[e] == sv[e + 1]) s_lit = 1;
+  __syncthreads();
+  if (tid == 0) lit[q] = s_lit;
 }
 
 // LimitGroups(limit) for limit > 63 (the CLI's default is 5 % of the groups): only the `limit` nearest
@@ -189,18 +201,19 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
 // ok[q] = 0 if more than `cap` entries tie at the threshold (the caller then sorts everything).
 __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict__ cdist, int g, int limit, int cap,
                                                         int *__restrict__ nn, int stride,
-                                                        int *__restrict__ nn_cnt, int *__restrict__ ok) {
+                                                        int *__restrict__ nn_cnt, int *__restrict__ ok,
+                                                        int *__restrict__ lit) {
   extern __shared__ float sel_lds[];
   float *sv = sel_lds;                                     // [cap]
   int *si = reinterpret_cast<int *>(sel_lds + cap);        // [cap]
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_remaining;
-  __shared__ int s_count;
+  __shared__ int s_count, s_lit;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float *dq = cdist + (size_t)q * g;
   auto keyof = [&](int c) { const float v = dq[c]; return v != v ? 0x7F800000u : __float_as_uint(v); };   // NaN orders last
   const int want = min(limit, g);
-  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)want; s_count = 0; }
+  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)want; s_count = 0; s_lit = 0; }
   __syncthreads();
   unsigned mask = 0u;
   for (int shift = 24; shift >= 0; shift -= 8) {
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   const unsigned thr = s_prefix;                           // key of the want-th smallest distance
   for (int c = tid; c < g; c += 256) {
     const unsigned key = keyof(c);
+    if (dq[c] != dq[c]) s_lit = 1;                         // NaN distance: literal heap (gq_literal_groups)
     if (key <= thr) {
       const int p = atomicAdd(&s_count, 1);
       if (p < cap) { sv[p] = __uint_as_float(key); si[p] = c; }
@@ -257,7 +271,94 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
       __syncthreads();
     }
   for (int e = tid; e < want; e += 256) nn[(size_t)q * stride + e] = si[e];
-  if (tid == 0) { nn_cnt[q] = want; ok[q] = 1; }
+  // equal distances among the searched groups or at the cut (every entry at the threshold was compacted, so a tie
+  // there shows as cnt > want): the reference's heap order decides, not (distance, id) -- gq_literal_groups
+  for (int e = tid; e + 1 < min(want + 1, cnt); e += 256)
+    if (sv[e] == sv[e + 1]) s_lit = 1;
+  __syncthreads();
+  if (tid == 0) { nn_cnt[q] = want; ok[q] = 1; lit[q] = s_lit; }
+}
+
+// exactNearestNeighbours(centroids, query, cap).deleteAll() (Index.scala:209-229, :287,:290) LITERALLY, for the
+// queries gq_sorted_groups / gq_select_groups flagged: a TopKHeap of capacity `cap` (LimitGroups: the limit;
+// LimitVectors: all g groups) in LDS, fed the centroid distances in index order, drained in place like heapsort
+// (deleteAll fills its result from the back: slot `size` is free the moment delete() returns).  One wavefront per
+// query; every lane runs the same scalar heap code on the same LDS words (stores of equal values, broadcast reads)
+// and only the scan for centroids the heap would take is spread over the lanes.
+__global__ __launch_bounds__(64) void gq_literal_groups(const float *__restrict__ cdist, int g, int cap,
+                                                        const int *__restrict__ bounds, int by_vectors, int limit,
+                                                        const int *__restrict__ lit, int *__restrict__ nn, int stride,
+                                                        int *__restrict__ nn_cnt) {
+  extern __shared__ float lg_lds[];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (!lit[q]) return;
+  volatile float *hv = lg_lds;                                  // [cap]
+  volatile int *hk = reinterpret_cast<volatile int *>(lg_lds + cap);   // [cap]
+  const float *dq = cdist + (size_t)q * g;
+  bool has_nan = false;
+  for (int c = lane; c < g; c += 64) has_nan = has_nan || dq[c] != dq[c];
+  has_nan = __any(has_nan);
+  int size = 0;
+  auto swp = [&](int a, int b) {
+    const float va = hv[a], vb = hv[b];
+    const int ka = hk[a], kb = hk[b];
+    hv[a] = vb; hk[a] = kb; hv[b] = va; hk[b] = ka;
+  };
+  auto down = [&](int i) {                                      // percolateDown, TopKHeap.scala:30-42
+    for (;;) {
+      int top = i;
+      const int lc = 2 * i + 1, rc = 2 * i + 2;
+      if (lc < size && hv[top] < hv[lc]) top = lc;
+      if (rc < size && hv[top] < hv[rc]) top = rc;
+      if (top == i) break;
+      swp(i, top);
+      i = top;
+    }
+  };
+  auto del = [&]() {                                            // delete, TopKHeap.scala:57-67
+    size -= 1;
+    const int removed = hk[0];
+    const float lv = hv[size];
+    const int lk = hk[size];
+    hv[0] = lv; hk[0] = lk;
+    down(0);
+    return removed;
+  };
+  for (int base = 0; base < g; base += 64) {
+    const bool have = base + lane < g;
+    const float dv = have ? dq[base + lane] : 0.f;
+    // with a NaN around the heap is not ordered and every centroid goes through update; otherwise its root only falls
+    unsigned long long mk = __ballot(have && (has_nan || size < cap || hv[0] > dv));
+    while (mk) {
+      const int l = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      const float x = readlane_f(dv, l);
+      if (size == cap && hv[0] > x) del();                      // update, TopKHeap.scala:69-79
+      if (size < cap) {
+        hv[size] = x; hk[size] = base + l;
+        int i = size;
+        while (i > 0) {                                         // percolateUp, TopKHeap.scala:21-28
+          const int p = (i - 1) / 2;
+          if (hv[i] > hv[p]) { swp(i, p); i = p; } else break;
+        }
+        size += 1;
+      }
+    }
+  }
+  const int live = size;
+  for (int j = live - 1; j >= 0; j--) {                         // deleteAll(): result(j) = delete(), j descending
+    const int kk = del();
+    hk[j] = kk;                                                 // slot j == size: outside the heap now
+  }
+  int cnt = live;
+  if (by_vectors) {                                             // searchSpace, Index.scala:289-298
+    int i = 0, count = 0;
+    while (i < live && count < limit) { const int c = hk[i]; count += bounds[c + 1] - bounds[c]; i++; }
+    cnt = i;
+  }
+  cnt = min(cnt, stride);
+  for (int e = lane; e < cnt; e += 64) nn[(size_t)q * stride + e] = hk[e];
+  if (lane == 0) nn_cnt[q] = cnt;
 }
 
 // ---- one searched group of one query -------------------------------------------------------------
@@ -724,8 +825,9 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     if (d_oc) HIP_CHECK(hipMemsetAsync(d_oc, 0, sizeof(int) * (size_t)B, st));
     return;
   }
-  // groups searched per query: at most `nn_stride` (LimitVectors: every group holds >= 1 row)
-  const int nn_stride = std::max(1, std::min(limit, g));
+  // groups searched per query: at most `nn_stride` (LimitVectors: every non-empty group holds >= 1 row; the
+  // reference's leading empty group adds nothing to the count and is searched on top)
+  const int nn_stride = std::max(1, (int)std::min<long long>((long long)limit + (strategy == 1 ? gx->n_empty : 0), g));
   int stride = nn_stride;
   gx->cdist.ensure((size_t)B * g);
   gx->nn.ensure((size_t)B * nn_stride);
@@ -743,6 +845,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_sorted_groups),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int *done = nullptr;
+    gx->lit_flag.ensure((size_t)B);
     if (strategy == 0 && limit >= 1 && limit * 4 <= g) {
       // few of many: radix-select + sort of the selected; the full sort only runs for queries it gave up on
       int cap = 256;
@@ -752,11 +855,23 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_select_groups),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
       hipLaunchKernelGGL(gq_select_groups, dim3(B), dim3(256), sel_lds, st, gx->cdist.p, g, limit, cap, gx->nn.p,
-                         nn_stride, gx->nn_cnt.p, gx->sel_ok.p);
+                         nn_stride, gx->nn_cnt.p, gx->sel_ok.p, gx->lit_flag.p);
       done = gx->sel_ok.p;
     }
     hipLaunchKernelGGL(gq_sorted_groups, dim3(B), dim3(256), lds, st, gx->cdist.p, g, n2, gx->bounds.p, strategy == 1,
-                       limit, gx->nn.p, nn_stride, gx->nn_cnt.p, done);
+                       limit, gx->nn.p, nn_stride, gx->nn_cnt.p, done, gx->lit_flag.p);
+    {
+      // queries whose answer hangs on equally distant centroids (or NaN distances): the reference's heap, literally
+      const int hcap = strategy == 1 ? g : std::min(limit, g);
+      if (hcap >= 1) {
+        const size_t hl = (size_t)hcap * 8;
+        GULON_UNSUPPORTED(hl > 144 * 1024, "%d groups: the literal heap needs %zu B of LDS (> 144 KiB)", hcap, hl);
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_literal_groups),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+        hipLaunchKernelGGL(gq_literal_groups, dim3(B), dim3(64), hl, st, gx->cdist.p, g, hcap, gx->bounds.p, strategy == 1,
+                           limit, gx->lit_flag.p, gx->nn.p, nn_stride, gx->nn_cnt.p);
+      }
+    }
     if (strategy == 1 && nn_stride > 64) {
       // LimitVectors rarely needs more than a handful of groups: size the per-group heaps by the
       // largest count of this batch (one small read-back) instead of by the worst case
@@ -923,6 +1038,7 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
     }
     bounds[g] = n;
     std::unique_ptr<gulon_grouped_index> gx(new gulon_grouped_index());
+    for (int c = 0; c < g; c++) gx->n_empty += bounds[c + 1] == bounds[c];
     gulon_index *pq = nullptr;
     int32_t rc = gulon_index_create(codes, n, d, m, k, pq_cents, 0, &pq);
     if (rc != GULON_OK) throw DeviceError{rc};

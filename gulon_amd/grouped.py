@@ -2,7 +2,7 @@
 (WordVectors.grouped / Grouped.residuals, WordVectors.scala:24-58,118-138).
 
 Build (CommandUtils.scala:127-147, command/BuildIndex): coarse KMeans on the full vectors ->
-`group` (par_assign + stable ordering by cluster, centroids of the non-empty clusters, group
+`group` (par_assign on the original order + stable ordering by word and cluster, group centroids, group
 offsets, residual matrix on the device) -> ProductQuantizer on the residuals -> `Index.grouped`.
 Row ids of a GroupedIndex are positions in the GROUPED order; `GroupedVectors.perm` maps them back.
 """
@@ -32,7 +32,7 @@ class LimitVectors:                    # GroupedIndex.Strategy.LimitVectors (Ind
 class GroupedVectors:
     """WordVectors.Grouped without the keys (those stay with the caller)."""
     perm: np.ndarray                   # grouped position -> original row
-    centroids: np.ndarray              # [g][d] centroids of the non-empty clusters, cluster order
+    centroids: np.ndarray              # [g][d] centroids of the groups (a leading empty group is possible, see group)
     offsets: np.ndarray                # [g-1] first grouped row of groups 1..g-1
     residuals: DeviceMatrix            # grouped row - its group's centroid, resident in HBM
 
@@ -44,24 +44,32 @@ class GroupedVectors:
         return int(np.searchsorted(self.offsets, i, side="right"))
 
 
-def group(vectors, clustering: KMeans) -> GroupedVectors:
-    """WordVectors.grouped (WordVectors.scala:24-58).  Rows keep their relative order inside a group
-    (the reference orders them by word first; pass rows that are already in word order)."""
+def group(vectors, clustering: KMeans, word_order=None) -> GroupedVectors:
+    """WordVectors.grouped (WordVectors.scala:24-58).
+
+    parAssign runs over the rows in the order given (the reference assigns BEFORE it sorts, so the
+    25 000-row tie-break streams see the original order, :27); `word_order` = row indices stably sorted by
+    word (:28-29; None: the rows are already in word order); rows are then stably ordered by cluster (:30).
+    The builder loop is seeded with the cluster of ORIGINAL row 0 (`prev = assignments(0)`, :38-39): when that
+    is not the lowest-numbered non-empty cluster the reference emits a leading empty group [0, 0) with a
+    copy of row 0's centroid -- reproduced here (offsets[0] == 0), since it changes what LimitGroups(m)
+    searches and what the index file holds."""
     if clustering.k <= 0:
         raise ValueError("requirement failed: must have at least 1 cluster")
     dm = as_device(vectors)
     assignments = clustering.par_assign(Vectors(dm))
-    perm = np.argsort(assignments, kind="stable").astype(np.int32)
+    n = len(assignments)
+    order = np.arange(n, dtype=np.int64) if word_order is None else np.asarray(word_order, np.int64)
+    perm = order[np.argsort(assignments[order], kind="stable")].astype(np.int32)
     sa = assignments[perm]
-    n = len(sa)
-    starts = np.flatnonzero(np.r_[True, sa[1:] != sa[:-1]]) if n else np.zeros(0, np.int64)
-    centroids = np.ascontiguousarray(N.f32(clustering.centroids)[sa[starts]]) if n else \
-        np.zeros((0, dm.cols), np.float32)
-    offsets = starts[1:].astype(np.int32)
-    g = len(starts)
-    group_of = (np.searchsorted(starts, np.arange(n), side="right") - 1).astype(np.int32)
     if n == 0:
-        return GroupedVectors(perm, centroids, offsets, dm)
+        return GroupedVectors(perm, np.zeros((0, dm.cols), np.float32), np.zeros(0, np.int32), dm)
+    change = np.r_[sa[0] != assignments[0], sa[1:] != sa[:-1]]          # `prev != a` at grouped position i
+    offsets = np.flatnonzero(change).astype(np.int32)
+    cent_ids = np.r_[assignments[0], sa[offsets]]
+    centroids = np.ascontiguousarray(N.f32(clustering.centroids)[cent_ids])
+    g = len(cent_ids)
+    group_of = np.searchsorted(offsets, np.arange(n), side="right").astype(np.int32)
     h = C.c_void_p()
     N.check(N.lib().gulon_dataset_group_residuals(dm._h, perm, group_of, centroids.reshape(-1), g, C.byref(h)))
     return GroupedVectors(perm, centroids, offsets, DeviceMatrix(h, dm.rows, dm.cols))

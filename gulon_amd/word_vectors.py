@@ -124,10 +124,11 @@ class WordVectors:
         """WordVectors.grouped (WordVectors.scala:24-58): rows ordered by (cluster, word); returns
         (GroupedWordVectors, gulon_amd.grouped.GroupedVectors) -- the second is what Index.grouped takes."""
         from .grouped import group
-        by_word = self.sorted()
-        gv = group(by_word.data, clustering)                 # stable by cluster: words stay ordered inside a group
-        words = [by_word.words[i] for i in gv.perm]
-        return GroupedWordVectors(words, by_word.data[gv.perm], gv.centroids, gv.offsets), gv
+        # parAssign over the rows as they are (:27), THEN the two stable sorts, by word and by cluster (:28-30)
+        order = np.asarray(sorted(range(self.size), key=lambda i: _jkey(self.words[i])), np.int64)
+        gv = group(self.data, clustering, word_order=order)
+        words = [self.words[i] for i in gv.perm]
+        return GroupedWordVectors(words, self.data[gv.perm], gv.centroids, gv.offsets), gv
 
 
 class GroupedWordVectors(WordVectors):

@@ -271,8 +271,9 @@ int32_t gulon_sharded_index_info(const gulon_sharded_index *idx, int32_t *n_shar
 /* ---- GroupedIndex (Index.scala:231-308): coarse groups + product-quantized residuals ---------
  * Rows are in GROUPED order (WordVectors.grouped, WordVectors.scala:24-58): stably ordered by the
  * coarse cluster they were assigned to; group c covers rows [offsets[c-1], offsets[c]) (first group
- * from 0, last to n); group_centroids holds the centroids of the g NON-EMPTY clusters, in cluster
- * order; the codes are the ProductQuantizer codes of the RESIDUALS (row - its group's centroid,
+ * from 0, last to n); group_centroids holds the centroids of the g groups as the reference's builder
+ * loop emits them (the non-empty clusters in cluster order, preceded by a copy of original row 0's
+ * centroid for an EMPTY group [0, 0) when row 0 is not in the first of them, :38-39); the codes are the ProductQuantizer codes of the RESIDUALS (row - its group's centroid,
  * WordVectors.Grouped.residuals :118-138).  Returned ids are grouped row positions.
  *
  * gulon_dataset_group_residuals builds that residual matrix on the device:
@@ -281,9 +282,11 @@ int32_t gulon_sharded_index_info(const gulon_sharded_index *idx, int32_t *n_shar
  * (:285-299; strategy 0 = LimitGroups(limit), 1 = LimitVectors(limit)), then for every searched
  * group, nearest first, PQIndex.query on (query - centroid) over the group's rows and
  * TopKHeap.merge into the result heap, then Result.fromHeap.  The heaps are the reference's,
- * literally (array order included), so ids and order equal the JVM's also under distance ties;
- * only the ORDER of equally distant coarse centroids under LimitVectors (or LimitGroups > 63)
- * follows (distance, id) instead of the heap's.  k_nn <= GULON_MAX_K. */
+ * literally (array order included), so ids and order equal the JVM's also under distance ties --
+ * equally distant coarse centroids included (they are common: WordVectors.grouped's leading empty
+ * group repeats a centroid, WordVectors.scala:38-39): queries whose searched groups hang on such a tie
+ * (or on a NaN distance) select their groups through the literal exactNearestNeighbours heap.
+ * Groups may be empty (offsets may repeat).  k_nn <= GULON_MAX_K. */
 typedef struct gulon_grouped_index gulon_grouped_index;
 int32_t gulon_dataset_group_residuals(const gulon_dataset *ds, const int32_t *perm, const int32_t *group_of,
                                       const float *group_centroids, int32_t g, gulon_dataset **out);

@@ -364,17 +364,34 @@ def exact_knn(X, Q, K, from_row=0, until_row=None):
     return oi, od, oc
 
 
-def group_rows(assignments, coarse_centroids):
-    """WordVectors.grouped (WordVectors.scala:24-58) on row ids: rows stably ordered by their coarse
-    assignment (the reference additionally orders by word inside a group -- callers pass rows that
-    are already in word order), the centroids of the NON-EMPTY clusters in cluster order and the
-    first row of groups 1..g-1.  Returns (perm, group_centroids [g][d], offsets [g-1])."""
+def group_rows(assignments, coarse_centroids, word_order=None):
+    """WordVectors.grouped (WordVectors.scala:24-58), restated literally on row ids.
+
+    `assignments` = clustering.parAssign over the rows in their ORIGINAL order (:27); `word_order` = the
+    row indices stably sorted by word (`Array.range(0, size).sortBy(word(_))`, :28-29; None: the rows are
+    already in word order); then the stable `.sortBy(assignments(_))` (:30) and the builder loop (:37-52),
+    INCLUDING its seed `prev = assignments(0)` (:38-39): that is the cluster of ORIGINAL row 0, not of the
+    first grouped row, so whenever row 0 is not in the lowest-numbered non-empty cluster the reference
+    emits a leading EMPTY group [0, 0) -- offsets(0) == 0 -- carrying a copy of row 0's centroid.
+    Returns (perm, group_centroids [g][d], offsets [g-1]) with g == len(offsets) + 1."""
     a = np.asarray(assignments, np.int32)
-    perm = np.argsort(a, kind="stable").astype(np.int32)
-    sa = a[perm]
-    starts = np.flatnonzero(np.r_[True, sa[1:] != sa[:-1]]) if len(sa) else np.zeros(0, np.int64)
-    cents = _f32(coarse_centroids)[sa[starts]] if len(sa) else _f32(coarse_centroids)[:0]
-    return perm, np.ascontiguousarray(cents), starts[1:].astype(np.int32)
+    n = len(a)
+    C_ = _f32(coarse_centroids)
+    order = np.arange(n) if word_order is None else np.asarray(word_order)
+    indices = order[np.argsort(a[order], kind="stable")]        # :28-30
+    offsets, cents = [], []
+    if n > 0:                                                   # :36
+        prev = int(a[0])                                        # :38
+        cents.append(C_[prev])                                  # :39
+        for i in range(n):                                      # :40-51
+            j = int(indices[i])
+            aj = int(a[j])
+            if prev != aj:
+                offsets.append(i)
+                prev = aj
+                cents.append(C_[prev])
+    gc = np.ascontiguousarray(np.stack(cents)) if cents else C_[:0]
+    return indices.astype(np.int32), gc, np.asarray(offsets, np.int32)
 
 
 def group_residuals(X, perm, group_centroids, offsets):

@@ -157,3 +157,56 @@ def test_many_groups_radix_select_of_the_nearest(oracle, g, dup):
         assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
         assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
     index.close()
+
+
+def test_row0_outside_the_first_cluster_gives_the_reference_empty_group(oracle, g):
+    """WordVectors.scala:38-39 seeds the builder with `assignments(0)`: when original row 0 is not in the
+    lowest-numbered non-empty cluster the reference emits a leading empty group [0, 0) with a copy of row 0's
+    centroid, which LimitGroups(m) then counts as one of the m searched groups."""
+    n, d, groups, m, k, K = 5000, 12, 9, 4, 16, 6
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=77)
+    assign = oracle.kmeans_assign(X, 0, d, coarse.centroids, rng_batch=25000)
+    if assign[0] == assign.min():                              # make sure the case is the interesting one
+        X[[0, int(np.argmax(assign != assign.min()))]] = X[[int(np.argmax(assign != assign.min())), 0]]
+        dm = g.DeviceMatrix.from_host(X)
+        gv = g.group(dm, coarse)
+        pq = g.ProductQuantizer.apply(gv.residuals, g.ProductQuantizerConfig(k, m, 3))
+        assign = oracle.kmeans_assign(X, 0, d, coarse.centroids, rng_batch=25000)
+    assert assign[0] != assign.min()
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    assert gv.offsets[0] == 0 and len(gv.centroids) == len(np.unique(assign)) + 1
+    assert np.array_equal(bits(gv.centroids[0]), bits(coarse.centroids[assign[0]]))
+    Q = X[[0, 5, 999, 4321]]
+    for strat, sid, limit in ((g.LimitGroups(1), 0, 1), (g.LimitGroups(2), 0, 2), (g.LimitVectors(700), 1, 700)):
+        index = g.Index.grouped(gv, pq, strat)
+        oi, od, oc = index.batch_query_raw(K, Q)
+        ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, sid, limit)
+        assert np.array_equal(oc, ec)
+        for q in range(len(Q)):
+            assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+            assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
+        index.close()
+
+
+def test_grouping_assigns_in_original_order_then_sorts_by_word(oracle, g):
+    """parAssign runs BEFORE the sorts (WordVectors.scala:27-30): with duplicate coarse centroids (init samples
+    with replacement) every row draws from the 25 000-row java.util.Random streams, which see the ORIGINAL
+    row order, not the word order."""
+    rng = np.random.default_rng(3)
+    n, d = 60000, 6
+    X = (rng.standard_normal((n, d)) + 3.0 * rng.integers(0, 3, (n, 1))).astype(np.float32)
+    C0 = X[[5, 5, 900, 900, 17, 5]].copy()                     # duplicates: exact distance ties for every row
+    coarse = g.KMeans(d, C0)
+    word_order = rng.permutation(n)                            # "sorted by word" is some other order than the rows'
+    dm = g.DeviceMatrix.from_host(X)
+    gv = g.group(dm, coarse, word_order=word_order)
+    assign = oracle.kmeans_assign(X, 0, d, C0, rng_batch=25000)
+    assert len(np.unique(assign)) > 3                          # the tie-break really spreads the rows
+    perm, cents, offsets = oracle.group_rows(assign, C0, word_order=word_order)
+    assert np.array_equal(perm, gv.perm) and np.array_equal(offsets, gv.offsets)
+    assert np.array_equal(bits(cents), bits(gv.centroids))
+    # assigning the word-sorted rows instead (what this repo did before) gives another grouping
+    assign_sorted = oracle.kmeans_assign(X[word_order], 0, d, C0, rng_batch=25000)
+    assert not np.array_equal(assign_sorted, assign[word_order])
+    R = oracle.group_residuals(X, perm, cents, offsets)
+    assert np.array_equal(bits(R), bits(gv.residuals.get_rows(np.arange(n, dtype=np.int32))))

@@ -37,8 +37,13 @@ def test_grouping_invariants_and_residuals(oracle, seed, n, d, groups):
     for c in np.unique(ga):                                           # stable: original order inside a group
         assert np.all(np.diff(perm[ga == c]) > 0)
     bounds = np.r_[0, offsets, n]
-    assert len(cents) == len(offsets) + 1 == len(np.unique(assign))   # only non-empty clusters
-    for gi in range(len(cents)):
+    # only non-empty clusters -- plus the reference's leading empty group when ORIGINAL row 0 is not in the
+    # lowest-numbered non-empty cluster (`prev = assignments(0)`, WordVectors.scala:38-39)
+    lead = int(assign[0] != assign.min())
+    assert len(cents) == len(offsets) + 1 == len(np.unique(assign)) + lead
+    if lead:
+        assert offsets[0] == 0 and np.array_equal(bits(cents[0]), bits(C[assign[0]]))
+    for gi in range(lead, len(cents)):
         rows = perm[bounds[gi]:bounds[gi + 1]]
         assert len(rows) > 0 and len(set(assign[rows])) == 1
         assert np.array_equal(bits(cents[gi]), bits(C[assign[rows[0]]]))
@@ -46,6 +51,25 @@ def test_grouping_invariants_and_residuals(oracle, seed, n, d, groups):
     # WordVectorsSpec.scala:109-123: centroid + residual is (nearly) the vector
     back = np.concatenate([R[bounds[gi]:bounds[gi + 1]] + cents[gi] for gi in range(len(cents))])
     assert np.allclose(back, X[perm], atol=0.05)
+
+
+def test_group_rows_is_the_reference_loop(oracle):
+    """Hand-worked cases of WordVectors.scala:24-58."""
+    C = np.arange(8, dtype=np.float32).reshape(4, 2)
+    # row 0 in the lowest non-empty cluster: no empty group
+    perm, cents, off = oracle.group_rows(np.array([1, 3, 1, 3, 2], np.int32), C)
+    assert perm.tolist() == [0, 2, 4, 1, 3] and off.tolist() == [2, 3] and cents.tolist() == C[[1, 2, 3]].tolist()
+    # row 0 in cluster 3, lowest non-empty cluster is 1: leading empty group with centroid 3, which comes again later
+    perm, cents, off = oracle.group_rows(np.array([3, 1, 2, 1, 3], np.int32), C)
+    assert perm.tolist() == [1, 3, 2, 0, 4] and off.tolist() == [0, 2, 3] and cents.tolist() == C[[3, 1, 2, 3]].tolist()
+    # word order: rows sorted by word first (stable), then by cluster; prev still comes from ORIGINAL row 0
+    perm, cents, off = oracle.group_rows(np.array([2, 0, 2, 0], np.int32), C, word_order=[3, 2, 1, 0])
+    assert perm.tolist() == [3, 1, 2, 0] and off.tolist() == [0, 2] and cents.tolist() == C[[2, 0, 2]].tolist()
+    # one cluster, no rows
+    perm, cents, off = oracle.group_rows(np.array([2, 2, 2], np.int32), C)
+    assert perm.tolist() == [0, 1, 2] and off.tolist() == [] and cents.tolist() == C[[2]].tolist()
+    perm, cents, off = oracle.group_rows(np.zeros(0, np.int32), C)
+    assert len(perm) == 0 and len(off) == 0 and len(cents) == 0
 
 
 def _numpy_grouped_query(oracle, codes, d, k, pq_cents, cents, offsets, q, K, strategy, limit):
