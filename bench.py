@@ -27,6 +27,122 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def run_steps(torch, shardeds, streams, Q, B, K, steps):
+    """`steps` timed batches round-robin over the workspaces (after one untimed round); ms per step + last outputs."""
+    nfl = len(shardeds)
+    out = None
+    for i in range(nfl):
+        with torch.cuda.stream(streams[i]):
+            shardeds[i].complete()
+            out = shardeds[i].batch_query_dev(Q, B, K)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for s_ in range(steps):
+        i = s_ % nfl
+        with torch.cuda.stream(streams[i]):
+            shardeds[i].complete()
+            out = shardeds[i].batch_query_dev(Q, B, K)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    return ms, tuple(x.cpu().numpy() for x in out)
+
+
+def extras(args, g, N, L, torch, dev, HipEngine, ShardedIndex, local_shard, recall_at_k, sample_rows, dm, pq, shard,
+           shardeds, streams, engines, Q, note):
+    """Sub-records of the same JSON line (rank 0, one GPU): the cases that are NOT favourable to the pruning
+    scan, and BASELINE config 3's k-means kernels, each over a few steps."""
+    import ctypes as C
+    n, d, m, k, B, K = args.rows, args.dim, args.quantizers, args.clusters, args.batch, args.knn
+    steps = max(1, args.extra_steps)
+    ex = {}
+
+    def stats(engs, out):
+        oi, od, oc, of = out
+        tiles, redone = C.c_int32(0), C.c_int32(0)
+        N.check(L.gulon_index_filter_stats(engs[-1 if len(engs) == 1 else (steps - 1) % len(engs)].index._h,
+                                           C.byref(tiles), C.byref(redone)))
+        return {"tie_flagged_queries": int(((of & 3) != 0).sum()), "replayed_queries": int(((of & 4) != 0).sum()),
+                "query_tiles": tiles.value, "tiles_redone_by_exact_scan": redone.value}
+
+    # 1. the exact scan (every look-up in fp32, no 8-bit filter): the path small ranges, wide indexes and the
+    #    safety net take
+    N.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 0))
+    try:
+        ms, _ = run_steps(torch, shardeds, streams, Q, B, K, min(steps, 3))
+    finally:
+        N.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 1))
+    ex["exact_scan"] = {"ms_per_step": ms, "queries_per_s": B / ms * 1e3,
+                        "what": "GULON_SCAN_FILTER=0: same index and queries, every (query,row,quantizer) look-up in fp32"}
+    note("extras: exact scan")
+    # 2. held-out queries: rows n .. n+B of the same generator (same centres; none of them is in the index)
+    big = g.DeviceMatrix.synthetic(n + B, d, args.data_kind, 1234, 1000)
+    Qho_h = big.get_rows(np.arange(n, n + B, dtype=np.int32))
+    del big
+    Qho = torch.from_numpy(Qho_h).to(dev)
+    ms, out = run_steps(torch, shardeds, streams, Qho, B, K, steps)
+    rec = {"ms_per_step": ms, "queries_per_s": B / ms * 1e3,
+           "what": f"queries = rows {n}..{n + B} of the same generator (not in the index)"}
+    rec.update(stats(engines, out))
+    if not args.no_recall:
+        rec["recall_at_%d" % K], rec["recall_sd"] = recall_at_k(dm, Qho_h, K, out[0], out[2])
+    ex["held_out_queries"] = rec
+    note("extras: held-out queries")
+    # 3. other data: kind 0 (iid N(0,1): PQ codes close to uniform, bounds separate least) and kind 1 (the
+    #    reference-shaped generator: every row of a cluster shares its PQ code, every query ties)
+    for kind in (0, 1):
+        t0 = time.perf_counter()
+        dmk = g.DeviceMatrix.synthetic(n, d, kind, 1234, 1000)
+        pqk = g.ProductQuantizer.apply(dmk, g.ProductQuantizerConfig(k, m, args.train_iters))
+        enck = pqk.encode(dmk)
+        e0 = HipEngine(pqk, local_shard(pqk, enck, 0, n), 0, dev)
+        engs = [e0] + [HipEngine(pqk, None, 0, dev, parent=e0) for _ in range(len(shardeds) - 1)]
+        shs = [ShardedIndex(e, n, 0, 1, None, False) for e in engs]
+        build_s = time.perf_counter() - t0
+        qr = sample_rows(n, B, 0)
+        Qk_h = dmk.get_rows(qr)
+        Qk = torch.from_numpy(Qk_h).to(dev)
+        ms, out = run_steps(torch, shs, streams, Qk, B, K, steps)
+        rec = {"ms_per_step": ms, "queries_per_s": B / ms * 1e3, "build_seconds": build_s,
+               "what": {0: "data kind 0: iid N(0,1) rows", 1: "data kind 1: 1000 tight clusters (the reference's generator shape): "
+                        "rows of a cluster share their PQ code, every query is an exact tie"}[kind]}
+        rec.update(stats(engs, out))
+        if not args.no_recall:
+            rec["recall_at_%d" % K], rec["recall_sd"] = recall_at_k(dmk, Qk_h, K, out[0], out[2])
+        ex[f"data_kind_{kind}"] = rec
+        for e in engs[1:] + engs[:1]:
+            e.index.close()
+        del shs, engs, e0, enck, pqk, dmk
+        note(f"extras: data kind {kind}")
+    # 4. BASELINE config 3: k-means codebook training, 10 M x 300, m = 32 (sub-dimensions 12 x 10 + 20 x 9), k = 256
+    c3n, c3d, c3m, c3k, c3it = int(os.environ.get("GULON_BENCH_C3_ROWS", "10000000")), 300, 32, 256, 2
+    dm3 = g.DeviceMatrix.synthetic(c3n, c3d, 2, 1234, 1)
+    N.check(L.gulon_kmeans_trace(1))
+    t0 = time.perf_counter()
+    g.ProductQuantizer.apply(dm3, g.ProductQuantizerConfig(c3k, c3m, c3it))
+    train_s = time.perf_counter() - t0
+    tot = N.KMeansTraceTotals()
+    N.check(L.gulon_kmeans_trace_read(C.byref(tot)))
+    N.check(L.gulon_kmeans_trace(0))
+    del dm3
+    it = max(tot.iterations, 1)
+    MFMA_F32_PEAK = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak, TFLOP/s
+    a_tf = tot.mfma_flops / (tot.assign_ms * 1e-3) / 1e12 if tot.assign_ms > 0 else 0.0
+    u_gb = tot.update_bytes / (tot.update_ms * 1e-3) / 1e9 if tot.update_ms > 0 else 0.0
+    ex["c3_kmeans"] = {
+        "workload": f"{c3n}x{c3d} U[0,1), ProductQuantizer.apply m={c3m} k={c3k}, {it} iterations timed "
+                    "(update -> parAssign -> convergence test), stages closed by device synchronisation",
+        "train_seconds_total": train_s, "iterations": tot.iterations,
+        "ms_per_iteration": {"update": tot.update_ms / it, "assign_mfma": tot.assign_ms / it,
+                             "exact_recheck_and_tie_replay": tot.recheck_ms / it, "converged_test": tot.converge_ms / it},
+        "assign_mfma": {"bound": "mfma", "achieved": a_tf, "peak": MFMA_F32_PEAK, "unit": "TFLOP/s",
+                        "frac": a_tf / MFMA_F32_PEAK, "flops_per_iteration": tot.mfma_flops / it,
+                        "rows_rechecked_exactly": tot.rows_rechecked / max(tot.rows_total, 1.0)},
+        "update": {"bound": "hbm", "achieved": u_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u_gb / HBM_PEAK_GBS,
+                   "bytes_per_iteration": tot.update_bytes / it}}
+    note("extras: C3 k-means")
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +159,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sub-records (exact scan, held-out queries, data kinds 0 and 1, C3 k-means)")
+    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of every sub-record")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GULON_BENCH_INFLIGHT", "0")),
                     help="query batches in flight (each on its own stream with its own scratch)")
     args = ap.parse_args()
@@ -213,14 +332,33 @@ def main():
     qps = B * args.steps / elapsed
     alg_bytes = float(B) * rows_per_launch * m            # m code bytes per (query, row) pair
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic = None
+    # physical side of the same kernel: HBM bytes and LDS / VALU counters per launch come from the committed
+    # rocprofv3 --pmc passes of this very command (profiles/scan_traffic.json names the csv they were read from);
+    # the duration they are divided by is the one measured live above
+    traffic, physical = None, None
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf)).get(f"{kernel_name}_n{nloc}_m{m}_B{B}")
             traffic = rec["hbm_bytes_per_launch"] if rec else None
+            if rec and scan_ms > 0:
+                hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
+                physical = {"hbm": {"bytes_per_launch": traffic, "GB_per_s": hbm_gbs, "peak_GB_per_s": HBM_PEAK_GBS,
+                                    "frac": hbm_gbs / HBM_PEAK_GBS,
+                                    "traffic_over_algorithmic": traffic / alg_bytes if alg_bytes else None},
+                            "source": rec.get("source")}
+                if "lds_idx_active" in rec:
+                    cyc = rec["grbm_gui_active"] / 8.0                       # kernel cycles (sum over 8 XCDs / 8)
+                    free = (rec["lds_idx_active"] - rec["lds_bank_conflict"]) / rec.get("cus", 256)
+                    physical["lds"] = {
+                        "bound": "LDS gather (ds_read_b128 of 16 one-byte bounds per look-up)",
+                        "conflict_free_cycles_per_cu": free, "kernel_cycles": cyc, "frac": free / cyc,
+                        "pipe_busy": rec["lds_idx_active"] / rec.get("cus", 256) / cyc,
+                        "bank_conflict_share": rec["lds_bank_conflict"] / rec["lds_idx_active"]}
+                if "valu_busy" in rec:
+                    physical["valu_busy"] = rec["valu_busy"]
         except Exception:
-            traffic = None
+            traffic, physical = None, None
 
     res_idx = out_idx.cpu().numpy()
     res_cnt = out_cnt.cpu().numpy()
@@ -234,11 +372,19 @@ def main():
         "config": {"workload": f"{n}x{d} synthetic (kind {args.data_kind}, 1000 centres, seed 1234), PQ(m={m},k={k}) flat ADC scan, batch={B}, K={K}, "
                                f"rows sharded over {world} GPU(s)", "n": n, "d": d, "m": m, "k": k, "batch": B,
                    "knn": K, "train_max_iterations": args.train_iters, "rows_per_gpu": nloc,
-                   "batches_in_flight": nfl},
+                   "batches_in_flight": nfl,
+                   "dist_backend": dist.get_backend() if dist is not None else None,
+                   "dist_world_size": dist.get_world_size() if dist is not None else 1,
+                   "tie_replay_extra_rounds": extra_rounds[0]},
+        # contract fields: ALGORITHMIC bytes (m code bytes per (query, row) pair) over the kernel's
+        # duration against the HBM peak.  The kernel reads every code word once per 16-query tile out of
+        # L2 / Infinity Cache and decides > 99.9 % of the pairs on 8-bit bounds, so this "fraction" exceeds 1 and
+        # bounds nothing; `physical` holds the bounds that bind (HBM actually moved; the LDS gather pipe)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                      "kernel_ms": scan_ms, "launches_per_step": launches.value / max(args.steps, 1),
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": alg_bytes, "basis": "algorithmic bytes, not DRAM traffic",
+                     "physical": physical},
         "build_seconds": build_s,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
     }
@@ -254,6 +400,9 @@ def main():
             result["recall_seconds"] = time.perf_counter() - t
             result["tie_flagged_queries"] = int((res_flg != 0).sum())
             note("recall done")
+        if world == 1 and enc is not None and not args.no_extras:
+            result["extras"] = extras(args, g, N, L, torch, dev, HipEngine, ShardedIndex, local_shard, recall_at_k,
+                                      sample_rows, dm, pq, shard, shardeds, streams, engines, Q, note)
         if world == 1 and enc is not None and not args.no_cpu_baseline:
             from oracle import oracle                      # CPU baseline leg only (the checker, timed)
             codes_h = np.stack(enc.encodings) if coder.width == 8 else None

@@ -707,6 +707,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   ix->sv_queue.ensure((size_t)Bq * NSLOT * cap);
   ix->fb_tile.ensure((size_t)ntiles);
   ix->tau0.ensure((size_t)Bp);
+  ix->last_filter_tiles = ntiles;
   if (phase != 2) {
     const int most = std::max(std::max(Bp, ntiles), Bq * NSLOT);
     hipLaunchKernelGGL(filter_reset, dim3(ceil_div(most, 256)), dim3(256), 0, st, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,

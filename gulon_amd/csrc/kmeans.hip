@@ -696,6 +696,8 @@ static void step_stats(const float *prev, const float *next, int k, int s, gulon
   r->step_s = ss;
 }
 
+TrainTrace &train_trace() { static TrainTrace t; return t; }
+
 // KMeans.computeClusters (KMeans.scala:134-157) for `np` independent problems
 // (from[p], s[p], seed[p]) over the same n x ld data, run iteration-synchronously: every
 // problem owns a stream and a workspace, so the small latency-bound kernels (sequential
@@ -705,14 +707,19 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
                         int k, int max_iterations, float *const *c_out, gulon_kmeans_report *reports,
                         int max_reports, int32_t *n_reports) {
   GULON_REQUIRE(n >= 1, "KMeans.init needs at least one row (n = %d)", n);   // rng.nextInt(0) throws on the JVM
-  const bool trace = getenv("GULON_TRACE") != nullptr;
+  const bool print = getenv("GULON_TRACE") != nullptr;
+  TrainTrace &tt = train_trace();
+  const bool trace = print || tt.on;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = now();
-  auto lap = [&](const char *what) {
+  // stage timing (GULON_TRACE=1 prints it, gulon_kmeans_trace collects it): a device synchronisation closes
+  // every stage, so the stages of the m concurrent problems are timed as a whole, one after the other
+  auto lap = [&](const char *what, double *acc = nullptr) {
     if (!trace) return;
     (void)hipDeviceSynchronize();
     double t = now();
-    fprintf(stderr, "[gulon trace] %-28s %8.2f ms\n", what, t - t_mark);
+    if (print) fprintf(stderr, "[gulon trace] %-28s %8.2f ms\n", what, t - t_mark);
+    if (acc && tt.on) *acc += t - t_mark;
     t_mark = t;
   };
   struct Prob {
@@ -811,7 +818,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
       descs.push_back(make_upd_desc(P[p].ws, P[p].xs.p, sdim[p], n, k, 0, sdim[p], P[p].a_prev.p, P[p].c_next.p));
     kmeans_update_batch(descs, d_descs.p, n, k, bst);
     HIP_CHECK(hipEventRecord(upd_done, bst));
-    lap("  update batch");
+    lap("  update batch", &tt.update_ms);
     for (int p : act) {
       Prob &pr = P[p];
       HIP_CHECK(hipStreamWaitEvent(pr.st, upd_done, 0));
@@ -819,14 +826,24 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
       make_job(p, pr.c_next.p, pr.a_next.p);
       assign_stage1(pr.job);
     }
-    lap("  assign stage1");
+    lap("  assign stage1", &tt.assign_ms);
     finish_assigns(act);
-    lap("  assign stages 2-3");
+    lap("  assign stages 2-3", &tt.recheck_ms);
     if (trace) {
       unsigned long long fl = 0, dr = 0;
-      for (int p : act) { fl += P[p].ws.last_flagged; dr += P[p].ws.last_draws; }
-      fprintf(stderr, "[gulon trace]   rows re-checked exactly %llu of %llu (%.3g), tie draws %llu\n", fl,
-              (unsigned long long)n * act.size(), (double)fl / ((double)n * act.size()), dr);
+      double fm = 0, ub = 0;
+      for (int p : act) {
+        fl += P[p].ws.last_flagged; dr += P[p].ws.last_draws;
+        if (P[p].use_mfma) fm += 2.0 * n * k * sdim[p];
+        ub += 4.0 * n * sdim[p];
+      }
+      if (print)
+        fprintf(stderr, "[gulon trace]   rows re-checked exactly %llu of %llu (%.3g), tie draws %llu\n", fl,
+                (unsigned long long)n * act.size(), (double)fl / ((double)n * act.size()), dr);
+      if (tt.on) {
+        tt.iterations++; tt.rows_rechecked += fl; tt.rows_total += (unsigned long long)n * act.size();
+        tt.mfma_flops += fm; tt.update_bytes += ub;
+      }
     }
     std::vector<unsigned> h_mism(np, 0);
     for (int p : act) {
@@ -850,7 +867,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
       std::swap(pr.h_prev, pr.h_next);
       if (converged) pr.done = true; else all_conv = false;
     }
-    lap("  mismatch+reports");
+    lap("  mismatch+reports", &tt.converge_ms);
     if (all_conv) break;
     i++;
   }
@@ -863,6 +880,26 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
 }  // namespace gulon
 
 using namespace gulon;
+
+GULON_API int32_t gulon_kmeans_trace(int32_t enable) {
+  return guarded([&] {
+    TrainTrace &t = train_trace();
+    t = TrainTrace();
+    t.on = enable != 0;
+  });
+}
+
+GULON_API int32_t gulon_kmeans_trace_read(gulon_kmeans_trace_totals *out) {
+  return guarded([&] {
+    GULON_REQUIRE(out != nullptr, "out is null");
+    const TrainTrace &t = train_trace();
+    out->iterations = t.iterations;
+    out->update_ms = t.update_ms; out->assign_ms = t.assign_ms; out->recheck_ms = t.recheck_ms;
+    out->converge_ms = t.converge_ms;
+    out->mfma_flops = t.mfma_flops; out->update_bytes = t.update_bytes;
+    out->rows_rechecked = (double)t.rows_rechecked; out->rows_total = (double)t.rows_total;
+  });
+}
 
 static void check_slice(const gulon_dataset *ds, int from, int s, int k) {
   GULON_REQUIRE(ds != nullptr, "dataset is null");

@@ -45,6 +45,15 @@ struct KmeansWorkspace {
   void ensure(int n, int k, int s);
 };
 
+// stage times of kmeans_train_batch, accumulated over its iterations while enabled (gulon_kmeans_trace)
+struct TrainTrace {
+  bool on = false;
+  int iterations = 0;
+  double update_ms = 0, assign_ms = 0, recheck_ms = 0, converge_ms = 0;
+  double mfma_flops = 0, update_bytes = 0;
+  unsigned long long rows_rechecked = 0, rows_total = 0;
+};
+TrainTrace &train_trace();
 bool mfma_assign_supported(int s, int k);
 void pack_slice(const float *dX, int n, int ld, int from, int s, int k, PackedSlice &ps, hipStream_t st);
 void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float *dC, int k, int *d_assign,

@@ -702,6 +702,7 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   GULON_UNSUPPORTED(K > GULON_MAX_K && !final_out,
                     "k_nn = %d > GULON_MAX_K = %d is only supported for unsharded queries", K, GULON_MAX_K);
   if (B == 0) return;
+  if (!sb || sb->phase != 2) ix->last_filter_tiles = 0;
   if (sb && sb->phase == 1) {
     // first half of a query with shared bounds: ranges the filter does not take have no bounds to offer
     const int rbt = ceil_div(until, 64) - from / 64;
@@ -1117,6 +1118,23 @@ GULON_API int32_t gulon_index_profile_read_ex(gulon_index *idx, double *ms_total
   int32_t rc = gulon_index_profile_read(idx, ms_total, launches);
   if (rc == GULON_OK && rows_total) *rows_total = idx->prof_rows;
   return rc;
+}
+
+GULON_API int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tiles, int32_t *tiles_redone) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr, "index is null");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    HIP_CHECK(hipDeviceSynchronize());
+    const int nt = idx->last_filter_tiles;
+    int redone = 0;
+    if (nt > 0) {
+      std::vector<int> h((size_t)nt);
+      HIP_CHECK(hipMemcpy(h.data(), idx->fb_tile.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+      for (int v : h) redone += v != 0;
+    }
+    if (query_tiles) *query_tiles = nt;
+    if (tiles_redone) *tiles_redone = redone;
+  });
 }
 
 GULON_API int32_t gulon_scan_tuning(const char *key, int32_t value) {

@@ -68,6 +68,7 @@ struct gulon_index {
   // host-mapped word the filter's fallback launch sets when it had anything to do: sizes the next one
   int *fb_hint_h = nullptr, *fb_hint_d = nullptr;
   int fb_wide_left = 0;   // launches that stay wide after the word was last seen set
+  int last_filter_tiles = 0;   // query tiles of the last filtered batch on this handle (0: it took the exact scan)
   // ---- query contexts (gulon_index_context_create): a context BORROWS the read-only members of its parent
   // (codes, wcodes, cents, from, sdim) and owns every scratch buffer above, so batches in flight on
   // different streams / threads never share device scratch.  The parent stays alive until its last context

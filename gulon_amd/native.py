@@ -40,6 +40,13 @@ class KMeansReport(C.Structure):
                 ("step_count", C.c_int32), ("step_mean", C.c_float), ("step_s", C.c_float)]
 
 
+class KMeansTraceTotals(C.Structure):
+    """gulon_kmeans_trace_totals: stage times of the training loop (bench.py's C3 record)."""
+    _fields_ = [("iterations", C.c_int32), ("update_ms", C.c_double), ("assign_ms", C.c_double),
+                ("recheck_ms", C.c_double), ("converge_ms", C.c_double), ("mfma_flops", C.c_double),
+                ("update_bytes", C.c_double), ("rows_rechecked", C.c_double), ("rows_total", C.c_double)]
+
+
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
@@ -75,6 +82,8 @@ SIGNATURES = {
     "gulon_kmeans_iterate": (_i32, [_vp, _i32, _i32, _f32p, _i32, _i32, _f32p]),
     "gulon_kmeans_train": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32,
                                   C.POINTER(_i32)]),
+    "gulon_kmeans_trace": (_i32, [_i32]),
+    "gulon_kmeans_trace_read": (_i32, [C.POINTER(KMeansTraceTotals)]),
     "gulon_pq_train": (_i32, [_vp, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32, _vp]),
     "gulon_pq_encode": (_i32, [_vp, _i32, _i32, _f32p, _u8p]),
     "gulon_pq_train_range": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32, _vp]),
@@ -105,6 +114,7 @@ SIGNATURES = {
     "gulon_index_replay_collect_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "gulon_replay_apply_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_index_profile_read_ex": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(C.c_int64)]),
+    "gulon_index_filter_stats": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gulon_scan_tuning": (_i32, [C.c_char_p, _i32]),
     "gulon_nan_queries_fix_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_topk_merge": (_i32, [_f32p, _i32p, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),

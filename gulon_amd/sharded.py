@@ -57,7 +57,7 @@ class HipEngine:
         # parent: another HipEngine over the same shard -- this engine is then only a WORKSPACE (a query context,
         # gulon_index_context_create) over that engine's codes: one per batch in flight, no second copy in HBM
         self.index = PQIndex(pq, shard, row_base=row_base) if parent is None else parent.index.context()
-        self.nloc = shard.length
+        self.nloc = shard.length if shard is not None else parent.nloc
         # flagged queries per round of the exact tie replay: the first, unconditional round is sized for the
         # common case (a few ties per batch), later rounds (only when a batch needs them) take more at once
         self.replay_first, self.replay_more, self.replay_pool = N.REPLAY_MAX_FLAGGED, 128, N.REPLAY_POOL

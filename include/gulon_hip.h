@@ -134,6 +134,24 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
                            int32_t max_iterations, int32_t seed, float *c_out,
                            gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports);
 
+/* Stage times of the training loop for bench.py's k-means record (BASELINE config 3): while enabled, every
+ * stage of KMeans.computeClusters / ProductQuantizer.apply is closed by a device synchronisation and its wall
+ * time accumulated over the iterations (process-wide; not for concurrent trainings):
+ *   update   = KMeans.fromAssignment of all sub-quantizers (stable counting sort + sequential mean chains)
+ *   assign   = first stage of parAssign of all sub-quantizers: centroid prep + the MFMA filter kernel
+ *   recheck  = exact re-evaluation of the rows the filter flagged + java.util.Random tie replay
+ *   converge = Arrays.equals(prev, next) + ProgressReport
+ * mfma_flops = 2 n k s summed over the filtered sub-quantizers and iterations (2 n k d per PQ
+ * iteration); update_bytes = 4 n s summed likewise (n d 4 B per PQ iteration). */
+typedef struct {
+  int32_t iterations;
+  double update_ms, assign_ms, recheck_ms, converge_ms;
+  double mfma_flops, update_bytes;
+  double rows_rechecked, rows_total;
+} gulon_kmeans_trace_totals;
+int32_t gulon_kmeans_trace(int32_t enable);   /* resets the totals */
+int32_t gulon_kmeans_trace_read(gulon_kmeans_trace_totals *out);
+
 /* ---- ProductQuantizer (ProductQuantizer.scala) ----------------------------- */
 /* ProductQuantizer.apply / fromSubvectors (ProductQuantizer.scala:121-153), Config
  * (:107-111): m independent computeClusters, seed = quantizer index.
@@ -309,6 +327,10 @@ int32_t gulon_index_profile_read(gulon_index *idx, double *scan_ms_total, int32_
 /* Same, plus the number of rows the bracketed launches covered (the dominant kernel is the
  * quantized filter when it is active, the exact scan otherwise). */
 int32_t gulon_index_profile_read_ex(gulon_index *idx, double *ms_total, int32_t *launches, int64_t *rows_total);
+/* Of the last batch this handle ran through the quantized filter (synchronises the device): its query tiles
+ * and how many of them the device-side safety net redid with the exact scan (unusable bound or survivor-queue
+ * overflow).  query_tiles = 0: the batch took the exact scan. */
+int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tiles, int32_t *tiles_redone);
 /* Launch-shape / algorithm knobs of the scan, process-wide (tests and tuning experiments):
  * key = the name of the corresponding environment variable, e.g. "GULON_SCAN_FILTER" (0/1),
  * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
