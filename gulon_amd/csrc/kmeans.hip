@@ -14,6 +14,7 @@
 #include "kmeans.hpp"
 
 #include <chrono>
+#include <map>
 
 namespace gulon {
 
@@ -313,26 +314,25 @@ __global__ void narrow_assign_u8(const int *__restrict__ a, long long n, uint8_t
 // ---------------------------------------------------------------------------
 // update: stable counting sort by cluster, then sequential chains
 // ---------------------------------------------------------------------------
-constexpr int SORT_ROWS_PER_WAVE = 2048;
+constexpr int CHUNK_ROWS = 1024;   // rows per workgroup-chunk of the counting sort (256 per wave)
 
 // All update kernels take an array of per-problem descriptors and pick theirs with
 // blockIdx.y (z for the group scan), so the m sub-quantizers of a ProductQuantizer are
 // updated by ONE launch each: the sequential chains are latency-bound (k*s threads per
 // problem), and only running all problems' chains side by side fills the GPU.
 
-// per wave-chunk histogram: hist[chunk][k]
+// per chunk histogram: hist[chunk][k]
 __global__ __launch_bounds__(256) void sort_hist(const UpdDesc *__restrict__ descs, int n, int k) {
   const UpdDesc D = descs[blockIdx.y];
-  extern __shared__ unsigned sh[];  // 4 * k
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned *h = sh + wave * k;
-  for (int c = lane; c < k; c += 64) h[c] = 0;
-  long long chunk = (long long)blockIdx.x * 4 + wave;
-  long long r0 = chunk * SORT_ROWS_PER_WAVE;
-  long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
-  for (long long r = r0 + lane; r < r1; r += 64) atomicAdd(&h[D.assign[r]], 1u);
-  if (r0 < n)
-    for (int c = lane; c < k; c += 64) D.hist[(size_t)chunk * k + c] = h[c];
+  extern __shared__ unsigned sh[];  // k
+  for (int c = threadIdx.x; c < k; c += 256) sh[c] = 0;
+  __syncthreads();
+  const long long chunk = blockIdx.x;
+  const long long r0 = chunk * CHUNK_ROWS;
+  const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
+  for (long long r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&sh[D.assign[r]], 1u);
+  __syncthreads();
+  for (int c = threadIdx.x; c < k; c += 256) D.hist[(size_t)chunk * k + c] = sh[c];
 }
 
 // two-level exclusive scan of the per-chunk histograms (per cluster, over chunks):
@@ -371,90 +371,312 @@ __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngrou
     unsigned run = 0;
     for (int c = 0; c < k; c++) { D.start[c] = run; run += cnt[c]; }
   }
+  // clusters by descending size: update_chains is as slow as its longest chain, and the workgroups holding the
+  // longest ones should be the first to get a SIMD (rank by counting; k is small where this matters)
+  if (D.corder) {
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+      const unsigned mine = cnt[c];
+      int rank = 0;
+      for (int o = 0; o < k; o++) rank += cnt[o] > mine || (cnt[o] == mine && o < c);
+      D.corder[rank] = c;
+    }
+  }
 }
 
-// each wave places its chunk's rows in order: order[start[c] + rank] = row (stable).
-// The lanes holding the same cluster are found without a loop: one ballot per key bit, and the
-// AND of (bit set ? ballot : ~ballot) over the bits is the mask of lanes with an equal key; the
-// rank inside the cluster is the population count of that mask below the lane.
+// Stable placement of a chunk's rows: bucket position start[c] + rank <- the row's slice, rank = rows of the
+// same cluster before it (in row order).  The slices themselves move here -- xb[position] = slice of the row,
+// sp = s rounded up to even floats so that every bucket row starts 8-byte aligned -- because the chains that
+// follow are sequential per (cluster, dim): over row ids they were a random gather of 40-byte pieces (one
+// 64-byte sector each, 320 M sectors per full-PQ iteration at BASELINE config 3: the bound of the round-1
+// kernel); over the regrouped copy every chain streams contiguous memory.
+//
+// One workgroup per 1024-row chunk, wave w = rows [256 w, 256 w + 256) in four steps of 64:
+//   A  per-wave cluster counts.  The lanes holding the same cluster are found without a loop: one ballot per
+//      key bit, the AND of (bit set ? ballot : ~ballot) is the mask of lanes with an equal key;
+//   B  chunk-local exclusive scan over (cluster, wave) -> every wave's first position per cluster;
+//   C  placement: position = wave's running position + rank among the step's equal keys (popcount of the
+//      mask below the lane); same-wave LDS accesses execute in program order, so every lane of a cluster
+//      reads the running position before the cluster's first lane advances it;
+//   D  (STAGED) the chunk's slices were written to LDS in sorted order; they leave as contiguous runs -- one
+//      per cluster, chunk rows / k slices long -- instead of one scattered 40-byte store per row (12.8 GB in
+//      21 ms against ~5 ms at BASELINE config 3: partial-line stores do not combine).
+// STAGED needs k <= 1024 and sp <= 16 (LDS); otherwise the slices go straight to their positions.
+template <int SMAX /* 0: slices go straight to their positions; else staged, s <= SMAX */>
 __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits) {
+  constexpr bool STAGED = SMAX > 0;
+  constexpr int NV = STAGED ? SMAX : 1;
   const UpdDesc D = descs[blockIdx.y];
-  extern __shared__ unsigned sh[];  // 4 * k running positions
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned *run = sh + wave * k;
-  long long chunk = (long long)blockIdx.x * 4 + wave;
-  long long r0 = chunk * SORT_ROWS_PER_WAVE;
-  if (r0 >= n) return;
-  long long r1 = r0 + SORT_ROWS_PER_WAVE < n ? r0 + SORT_ROWS_PER_WAVE : n;
+  extern __shared__ unsigned sh[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned *wh = sh;                                  // [4][k] per-wave counts, then running positions
+  unsigned *gpos = sh + 4 * k;                        // STAGED: [k] bucket position of chunk-local position 0
+  int *dstrow = reinterpret_cast<int *>(sh + 5 * k);  // STAGED: [CHUNK_ROWS] bucket position of a local position
+  unsigned short *lpos = reinterpret_cast<unsigned short *>(sh + 5 * k + CHUNK_ROWS);   // STAGED: [CHUNK_ROWS] local position of a chunk row
+  float *sorted = reinterpret_cast<float *>(sh + ((5 * k + CHUNK_ROWS + CHUNK_ROWS / 2 + 1) & ~1));   // STAGED: [CHUNK_ROWS][sp], 8-byte aligned
+  __shared__ unsigned wave_tot[4];
+  const long long chunk = blockIdx.x;
+  const long long r0 = chunk * CHUNK_ROWS;
+  const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
   const long long grp = chunk / SCAN_GROUP;
-  for (int c = lane; c < k; c += 64)
-    run[c] = D.start[c] + D.gtot[(size_t)grp * k + c] + D.hist[(size_t)chunk * k + c];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  int key_next = r0 + lane < r1 ? D.assign[r0 + lane] : 0;
-  for (long long base = r0; base < r1; base += 64) {
-    const long long r = base + lane;
-    const bool valid = r < r1;
-    const int key = key_next;
-    if (base + 64 + lane < r1) key_next = D.assign[base + 64 + lane];
-    unsigned long long same = __ballot(valid);
-    for (int bit = 0; bit < key_bits; bit++) {
-      const unsigned long long bm = __ballot((key >> bit) & 1);
-      same &= ((key >> bit) & 1) ? bm : ~bm;
+  const int s = D.s, sp = (s + 1) & ~1;
+  // STAGED: the wave's 256 slices are 256 * s consecutive floats of the compact source = 64 * s float4: all of them
+  // requested now (s loads of 16 bytes per lane), consumed after the positions are known
+  float4 v[NV];
+  const long long wr0 = r0 + wave * 256;                          // first row of this wave
+  const int wrows = (int)max(0ll, min(256ll, r1 - wr0));          // its rows
+  if (STAGED) {
+    const float4 *src4 = reinterpret_cast<const float4 *>(D.x + (size_t)wr0 * s);
+    const int nf4 = wrows * s / 4, tail0 = nf4 * 4, total = wrows * s;   // whole float4s, then up to 3 floats
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int f = lane + 64 * u;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < s) {
+        if (f < nf4) v[u] = src4[f];
+        else if (f == nf4 && tail0 < total) {
+          const float *tp = D.x + (size_t)wr0 * s + tail0;
+          v[u].x = tp[0];
+          if (tail0 + 1 < total) v[u].y = tp[1];
+          if (tail0 + 2 < total) v[u].z = tp[2];
+        }
+      }
     }
-    // same-wave LDS accesses execute in program order: every lane of a cluster reads the
-    // running position before the cluster's first lane advances it
-    const unsigned b = valid ? run[key] : 0u;
-    if (valid) D.order[b + __popcll(same & lt)] = (int)r;
-    if (valid && (same & lt) == 0ull) run[key] = b + __popcll(same);
   }
+  for (int e = tid; e < 4 * k; e += 256) wh[e] = 0;
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // A: keys of this lane's four rows, per-wave counts
+  int keys[4];
+  unsigned long long same[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const long long r = wr0 + t * 64 + lane;
+    const bool valid = r < r1;
+    keys[t] = valid ? D.assign[r] : 0;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const bool valid = wr0 + t * 64 + lane < r1;
+    unsigned long long sm = __ballot(valid);
+    for (int bit = 0; bit < key_bits; bit++) {
+      const unsigned long long bm = __ballot((keys[t] >> bit) & 1);
+      sm &= ((keys[t] >> bit) & 1) ? bm : ~bm;
+    }
+    same[t] = valid ? sm : 0ull;
+    if (valid && (sm & lt) == 0ull) wh[wave * k + keys[t]] += (unsigned)__popcll(sm);   // only this wave touches wh[wave]
+  }
+  __syncthreads();
+  // B: first position of every (cluster, wave)
+  if (STAGED) {
+    // exclusive scan of the chunk's cluster totals: thread t owns clusters [t*per, t*per + per)
+    const int per = (k + 255) / 256;
+    unsigned mine = 0;
+    for (int c = tid * per; c < min(k, tid * per + per); c++)
+      mine += wh[c] + wh[k + c] + wh[2 * k + c] + wh[3 * k + c];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned base = incl - mine;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    for (int c = tid * per; c < min(k, tid * per + per); c++) {
+      const unsigned t0 = wh[c], t1 = wh[k + c], t2 = wh[2 * k + c], t3 = wh[3 * k + c];
+      gpos[c] = D.start[c] + D.gtot[(size_t)grp * k + c] + D.hist[(size_t)chunk * k + c] - base;
+      wh[c] = base; wh[k + c] = base + t0; wh[2 * k + c] = base + t0 + t1; wh[3 * k + c] = base + t0 + t1 + t2;
+      base += t0 + t1 + t2 + t3;
+    }
+  } else {
+    for (int c = tid; c < k; c += 256) {
+      const unsigned t0 = wh[c], t1 = wh[k + c], t2 = wh[2 * k + c];
+      const unsigned base = D.start[c] + D.gtot[(size_t)grp * k + c] + D.hist[(size_t)chunk * k + c];
+      wh[c] = base; wh[k + c] = base + t0; wh[2 * k + c] = base + t0 + t1; wh[3 * k + c] = base + t0 + t1 + t2;
+    }
+  }
+  __syncthreads();
+  // C: placement
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const long long r = wr0 + t * 64 + lane;
+    const bool valid = r < r1;
+    const int key = keys[t];
+    const unsigned b = valid ? wh[wave * k + key] : 0u;
+    const unsigned pos = b + (unsigned)__popcll(same[t] & lt);
+    if (valid && (same[t] & lt) == 0ull) wh[wave * k + key] = b + (unsigned)__popcll(same[t]);
+    if (STAGED) {
+      if (valid) { dstrow[pos] = (int)(gpos[key] + pos); lpos[wave * 256 + t * 64 + lane] = (unsigned short)pos; }
+    } else if (valid) {
+      float *dst = D.xb + (size_t)pos * sp;
+      const float *src = D.x + (size_t)r * D.ld + D.from;
+      int j = 0;
+      for (; j + 2 <= s; j += 2) *reinterpret_cast<float2 *>(dst + j) = make_float2(src[j], src[j + 1]);
+      if (j < s) dst[j] = src[j];
+    }
+  }
+  if (!STAGED) return;
+  // every prefetched element to the chunk-local position of its row (same-wave LDS order: lpos is written above)
+  {
+    const unsigned rdiv = (65536u + (unsigned)s - 1u) / (unsigned)s;   // e / s == (e * rdiv) >> 16 for e < 4096, s <= 16
+    const int total = wrows * s;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      if (u < s) {
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+          const int e = 4 * (lane + 64 * u) + c4;
+          if (e < total) {
+            const int row = (int)(((unsigned)e * rdiv) >> 16);
+            const int j = e - row * s;
+            sorted[(size_t)lpos[wave * 256 + row] * sp + j] = vv[c4];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // D: sorted slices leave as float2 units; consecutive units of a cluster's run are consecutive in memory
+  const int h = sp >> 1;
+  const int units = (int)(r1 - r0) * h;
+  const unsigned hdiv = ((1u << 20) + (unsigned)h - 1u) / (unsigned)h;   // u / h == (u * hdiv) >> 20 for u < 8192, h <= 8
+  const float2 *src2 = reinterpret_cast<const float2 *>(sorted);
+  float2 *dst2 = reinterpret_cast<float2 *>(D.xb);
+  for (int u = tid; u < units; u += 256) {
+    const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
+    const int part = u - lp * h;
+    dst2[(size_t)dstrow[lp] * h + part] = src2[u];
+  }
+}
+
+// ---- the running mean's division, off the critical path ---------------------------------------------------
+// c <- c + (x - c)/n needs RN((x - c)/n), the correctly rounded quotient (what the JVM's float division gives).
+// __fdiv_rn is ~11 dependent instructions; the chain has nothing else to overlap them with (k*s chains per
+// problem: ~1.25 waves per SIMD at BASELINE config 3), so its latency IS the kernel's time.  With y = RN(1/n)
+// (a table: n is the step number, wave-uniform) Markstein's correction gives the same quotient in three
+// dependent operations:   q0 = RN(a y);  r = RN(a - n q0) (exact, one fma);  q = RN(q0 + r y)  ==  RN(a / n)
+// whenever y is the correctly rounded reciprocal and nothing under- or overflows (a faithful q0 plus one
+// fma-corrected step; Markstein 1990, Cornea-Harrison-Tang 2002).  mean_step_fast is only trusted for
+// 2^-60 < |a| < 2^60 (n <= 2^24: every intermediate stays normal); a batch in which any step falls outside is
+// recomputed with __fdiv_rn.  gulon_selftest_mean_division checks the identity against __fdiv_rn for EVERY
+// n in [1, 2^24) over random and near-halfway numerators (tests/test_gpu_kmeans.py).
+__device__ __forceinline__ float mean_quotient_fast(float a, float nf, float y) {
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-nf, q0, a);
+  return __builtin_fmaf(r, y, q0);
+}
+__device__ __forceinline__ bool mean_fast_ok(float a) {
+  const float m = fabsf(a);
+  return m > 8.673617379884035e-19f /* 2^-60 */ && m < 1.152921504606847e18f /* 2^60 */;
+}
+
+__global__ void rcp_table_kernel(float *__restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __fdiv_rn(1.0f, (float)(int)(i + 1));
+}
+
+// mismatches of mean_quotient_fast against __fdiv_rn: every divisor n in [1, n_max], `per` numerators each --
+// random ones and ones built to sit next to a rounding boundary (n times a random quotient, one ulp up and down)
+__global__ void mean_division_selftest(int n_max, int per, unsigned long long seed, unsigned long long *__restrict__ bad) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)n_max * per;
+  unsigned long long mism = 0;
+  for (long long w = t; w < total; w += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(w / per) + 1;
+    const int e = (int)(w % per);
+    unsigned long long z = seed + (unsigned long long)w * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    const float nf = (float)n;
+    // a random float with exponent in [-40, 40]
+    const unsigned mant = (unsigned)(z & 0x7FFFFF), sgn = (unsigned)((z >> 23) & 1);
+    const int ex = (int)((z >> 24) % 81) - 40;
+    float a = __uint_as_float((sgn << 31) | ((unsigned)(ex + 127) << 23) | mant);
+    if (e & 1) {   // a = RN(n * q) nudged by -1, 0, +1 ulp: quotients next to q and to its rounding boundaries
+      const float q = a;
+      a = nf * q;
+      const int nudge = (int)((z >> 40) % 3) - 1;
+      a = __uint_as_float(__float_as_uint(a) + (unsigned)nudge);
+    }
+    if (!mean_fast_ok(a)) continue;
+    const float y = __fdiv_rn(1.0f, nf);
+    const float fast = mean_quotient_fast(a, nf, y);
+    const float ref = __fdiv_rn(a, nf);
+    if (__float_as_uint(fast) != __float_as_uint(ref)) mism++;
+  }
+  if (mism) atomicAdd(bad, mism);
 }
 
 // one thread per (cluster, dim): c_j <- c_j + (x_j - c_j)/n over the cluster's rows
-// in row order (KMeans.scala:211-224).  IEEE division (__fdiv_rn), int->float RNE.
-// Two-level software pipeline: row ids two batches ahead, row values one batch ahead of the
-// sequential divide-add recurrence (neither load depends on the chain).
+// in row order (KMeans.scala:211-224); int->float RNE, correctly rounded quotient (above).
+// The cluster's slices are contiguous in xb (sort_place).  A three-deep software pipeline of 32-step batches
+// keeps 64 steps of loads in flight per lane (no load depends on the chain).  The kernel is one wave per 64
+// chains and there are barely more waves than SIMDs (1280 at BASELINE config 3, two on some SIMDs), so it is
+// as fast as its instruction stream is short: SP (the bucket row stride) is a template parameter so that every
+// load of a batch is one instruction with an immediate offset from a pointer that advances once per batch, the
+// main loop runs clear of the cluster's end (no index clamps), and the range test of the fast quotient is one
+// min and one max per step, looked at once per batch.
+template <int SP /* bucket row stride in floats; 0: read it from the descriptor */>
 __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ descs, int k) {
-  const UpdDesc D = descs[blockIdx.y];
-  const int s = D.s;
-  const float *__restrict__ X = D.x;
-  const int ld = D.ld;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const UpdDesc D = descs[blockIdx.x];            // x = problem, y = block of 64 chains: blocks are dispatched x-fastest,
+  const int s = D.s, sp = SP ? SP : ((s + 1) & ~1);   // so every problem's longest chains (block 0) come first
+  int t = blockIdx.y * blockDim.x + threadIdx.x;
   if (t >= k * s) return;
-  int c = t / s, j = t - c * s;
+  const int slot = t / s, j = t - slot * s;
+  const int c = D.corder ? D.corder[slot] : slot;
   const unsigned len = D.count[c];
-  const int *ord = D.order + D.start[c];
-  const float *col = X + D.from + j;
+  const float *__restrict__ rcp = D.rcp;
   float p = 0.f;
-  if (len == 0) { D.cout[t] = 0.f; return; }
-  constexpr int U = 16;
-  const unsigned nb = len / U;          // full batches
+  if (len == 0) { D.cout[c * s + j] = 0.f; return; }
+  const float *col = D.xb + (size_t)D.start[c] * sp + j;
+#ifdef GULON_CHAINS_EXPT
+  col = D.xb + (size_t)D.start[c] * sp;   // timing experiment: 10 lanes share an address
+#endif
+  constexpr int U = 32;
   const unsigned last = len - 1;
-  // every prefetch index is clamped to the last row of the cluster, so the loads are
-  // unconditional: a select-or-load per element makes hipcc branch around each load and
-  // wait for it individually (one exposed memory latency per step)
-  int o1[U];
-  float xa[U], xb[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) xa[u] = col[(size_t)ord[min((unsigned)u, last)] * ld];
-#pragma unroll
-  for (int u = 0; u < U; u++) o1[u] = ord[min((unsigned)(U + u), last)];
   unsigned i = 0;
-  for (unsigned b = 0; b < nb; b++) {
+  if (len >= 3 * U) {
+    float xa[U], xb[U], xc[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) xb[u] = col[(size_t)o1[u] * ld];
+    for (int u = 0; u < U; u++) xa[u] = col[(size_t)u * sp];
 #pragma unroll
-    for (int u = 0; u < U; u++) o1[u] = ord[min(i + 2 * U + u, last)];
+    for (int u = 0; u < U; u++) xb[u] = col[(size_t)(U + u) * sp];
+    const float *nxt = col + (size_t)2 * U * sp;
+    // batches whose look-ahead (two batches) stays inside the cluster
+    for (; i + 3 * U <= len; i += U, nxt += (size_t)U * sp) {
+#pragma unroll
+      for (int u = 0; u < U; u++) xc[u] = nxt[(size_t)u * sp];
+      const float p0 = p;
+      float lo = INFINITY, hi = 0.f;
+      float nf = (float)(int)(i + 1);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float a = xa[u] - p;
+        lo = fminf(lo, fabsf(a));
+        hi = fmaxf(hi, fabsf(a));
+        p = p + mean_quotient_fast(a, nf, rcp[i + u]);
+        nf += 1.0f;                                   // exact below 2^24
+      }
+      // a zero, tiny, huge or NaN numerator somewhere in the batch: the plain division, from the batch's start
+      if (!__all(lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */)) {
+        p = p0;
+#pragma unroll
+        for (int u = 0; u < U; u++) p = p + __fdiv_rn(xa[u] - p, (float)(int)(i + u + 1));
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) { xa[u] = xb[u]; xb[u] = xc[u]; }
+    }
+    // the two batches already in registers
 #pragma unroll
     for (int u = 0; u < U; u++) p = p + __fdiv_rn(xa[u] - p, (float)(int)(i + u + 1));
+    i += U;
 #pragma unroll
-    for (int u = 0; u < U; u++) xa[u] = xb[u];
+    for (int u = 0; u < U; u++) p = p + __fdiv_rn(xb[u] - p, (float)(int)(i + u + 1));
     i += U;
   }
-  for (; i < len; i++) {
-    float xv = col[(size_t)ord[i] * ld];
-    p = p + __fdiv_rn(xv - p, (float)(int)(i + 1));
-  }
-  D.cout[t] = p;
+  for (; i <= last; i++) p = p + __fdiv_rn(col[(size_t)i * sp] - p, (float)(int)(i + 1));
+  D.cout[c * s + j] = p;
 }
 
 // ---------------------------------------------------------------------------
@@ -480,13 +702,13 @@ void KmeansWorkspace::ensure(int n, int k, int s) {
   ties.ensure((size_t)std::max(n, 1));
   local.ensure((size_t)std::max(n, 1));
   tie_total.ensure(1);
-  long long nchunks = ceil_div(std::max(n, 1), SORT_ROWS_PER_WAVE);
-  long long nchunks_pad = ((nchunks + 3) / 4) * 4;
-  hist.ensure((size_t)nchunks_pad * k);
-  gtot.ensure((size_t)ceil_div(nchunks_pad, SCAN_GROUP) * k);
+  long long nchunks = ceil_div(std::max(n, 1), CHUNK_ROWS);
+  hist.ensure((size_t)nchunks * k);
+  gtot.ensure((size_t)ceil_div(nchunks, SCAN_GROUP) * k);
   count.ensure(k);
   start.ensure(k);
-  order.ensure((size_t)std::max(n, 1));
+  xb.ensure((size_t)std::max(n, 1) * (size_t)((s + 1) & ~1));
+  corder.ensure(k);
   mismatch.ensure(1);
 }
 
@@ -632,21 +854,68 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
   HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
   int smax = 1;
   for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
-  long long nchunks = ceil_div(n, SORT_ROWS_PER_WAVE);
-  int blocks = ceil_div(nchunks, 4);
+  long long nchunks = ceil_div(n, CHUNK_ROWS);
   long long ngroups = ceil_div(nchunks, SCAN_GROUP);
-  size_t shm = sizeof(unsigned) * 4 * (size_t)k;
-  GULON_UNSUPPORTED(shm > 160 * 1024, "k-means update with k = %d clusters needs %zu B of LDS for its per-cluster counters "
-                    "(> 160 KiB): train at most 10240 clusters per quantizer on the GPU", k, shm);
-  hipLaunchKernelGGL(sort_hist, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k);
+  bool compact = true;   // every problem reads a compact copy of its slice (ld == s): the staged placement's coalesced loads
+  for (const UpdDesc &D : descs) compact = compact && D.ld == D.s && D.from == 0;
+  const int sp_max = (smax + 1) & ~1;
+  const bool staged = compact && k <= 1024 && sp_max <= 16;
+  const size_t shm_hist = sizeof(unsigned) * (size_t)k;
+  const size_t shm_place = staged ? sizeof(unsigned) * (5 * (size_t)k + CHUNK_ROWS + CHUNK_ROWS / 2 + 2) + sizeof(float) * CHUNK_ROWS * (size_t)sp_max
+                                  : sizeof(unsigned) * 4 * (size_t)k;
+  GULON_UNSUPPORTED(shm_place > 160 * 1024, "k-means update with k = %d clusters needs %zu B of LDS for its per-cluster counters "
+                    "(> 160 KiB): train at most 10240 clusters per quantizer on the GPU", k, shm_place);
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm_hist));
+  hipLaunchKernelGGL(sort_hist, dim3((unsigned)nchunks, np), dim3(256), shm_hist, st, d_descs, n, k);
   hipLaunchKernelGGL(sort_scan_groups, dim3((unsigned)ngroups, ceil_div(k, 256), np), dim3(256), 0, st, d_descs,
                      nchunks, k);
   hipLaunchKernelGGL(sort_scan_top, dim3(1, np), dim3(256), sizeof(unsigned) * (size_t)k, st, d_descs, ngroups, k);
   int key_bits = 0;
   while ((1 << key_bits) < k) key_bits++;
-  hipLaunchKernelGGL(sort_place, dim3(blocks, np), dim3(256), shm, st, d_descs, n, k, key_bits);
-  hipLaunchKernelGGL(update_chains, dim3(ceil_div((long long)k * smax, 64), np), dim3(64), 0, st, d_descs, k);
+  auto place = !staged ? sort_place<0> : smax <= 4 ? sort_place<4> : smax <= 8 ? sort_place<8> : smax <= 12 ? sort_place<12>
+                                                                                                       : sort_place<16>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(place), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm_place));
+  hipLaunchKernelGGL(place, dim3((unsigned)nchunks, np), dim3(256), shm_place, st, d_descs, n, k, key_bits);
+  bool one_stride = true;   // every problem with the same bucket row stride: the chains take it as a constant
+  for (const UpdDesc &D : descs) one_stride = one_stride && ((D.s + 1) & ~1) == sp_max;
+  auto chains = !one_stride ? update_chains<0> : sp_max == 2 ? update_chains<2> : sp_max == 4 ? update_chains<4>
+              : sp_max == 6 ? update_chains<6> : sp_max == 8 ? update_chains<8> : sp_max == 10 ? update_chains<10>
+              : sp_max == 12 ? update_chains<12> : sp_max == 14 ? update_chains<14> : sp_max == 16 ? update_chains<16>
+              : update_chains<0>;
+  // one wave per workgroup; with more workgroups than SIMDs, 40 KiB of (unused) LDS each keeps four per CU -- one per
+  // SIMD at full issue rate -- and the rest, the SHORTEST chains (size order), start as the first ones finish
+  const int chain_blocks = ceil_div((long long)k * smax, 64);
+  int cus = 256;
+  { int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); }
+  static const int cap_env = [] { const char *e = getenv("GULON_CHAINS_PER_CU"); return e ? atoi(e) : 4; }();
+  size_t chain_lds = 0;
+  if (cap_env > 0 && (long long)chain_blocks * np > (long long)cap_env * cus) chain_lds = (size_t)(160 * 1024) / cap_env;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chains), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)std::max<size_t>(chain_lds, 1)));
+  hipLaunchKernelGGL(chains, dim3(np, chain_blocks), dim3(64), chain_lds, st, d_descs, k);
   HIP_CHECK(hipGetLastError());
+}
+
+// RN(1/i) for i = 1 .. n: shared by every problem on this device (grown on demand, never shrunk)
+static const float *rcp_table(int n) {
+  struct Tab { DevBuf<float> buf; };
+  static std::mutex mu;
+  static std::map<int, Tab> tabs;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  Tab &t = tabs[dev];
+  if ((size_t)n > t.buf.n) {
+    const long long want = std::max<long long>(n, 1024);
+    HIP_CHECK(hipDeviceSynchronize());   // nothing in flight may still read the table about to be replaced
+    t.buf.alloc((size_t)want);
+    hipLaunchKernelGGL(rcp_table_kernel, dim3((unsigned)ceil_div(want, 256)), dim3(256), 0, 0, t.buf.p, want);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  return t.buf.p;
 }
 
 // x/ld/from describe where row r's slice starts: x + r*ld + from
@@ -656,7 +925,9 @@ UpdDesc make_upd_desc(KmeansWorkspace &ws, const float *x, int ld, int n, int k,
   UpdDesc D;
   D.x = x; D.ld = ld;
   D.assign = d_assign; D.hist = ws.hist.p; D.gtot = ws.gtot.p; D.count = ws.count.p; D.start = ws.start.p;
-  D.order = ws.order.p; D.cout = dC; D.from = from; D.s = s;
+  D.xb = ws.xb.p; D.cout = dC; D.from = from; D.s = s;
+  D.rcp = rcp_table(n);
+  D.corder = k <= 2048 ? ws.corder.p : nullptr;
   return D;
 }
 
@@ -880,6 +1151,21 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
 }  // namespace gulon
 
 using namespace gulon;
+
+GULON_API int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed,
+                                               int64_t *mismatches) {
+  return guarded([&] {
+    GULON_REQUIRE(mismatches != nullptr && n_max >= 1 && n_max < (1 << 24) && numerators_per_divisor >= 1, "bad arguments");
+    DevBuf<unsigned long long> bad(1);
+    HIP_CHECK(hipMemset(bad.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(mean_division_selftest, dim3(8192), dim3(256), 0, 0, n_max, numerators_per_divisor,
+                       (unsigned long long)seed, bad.p);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long h = 0;
+    HIP_CHECK(hipMemcpy(&h, bad.p, sizeof(h), hipMemcpyDeviceToHost));
+    *mismatches = (int64_t)h;
+  });
+}
 
 GULON_API int32_t gulon_kmeans_trace(int32_t enable) {
   return guarded([&] {

@@ -17,9 +17,11 @@ struct PackedSlice {
 struct UpdDesc {
   const int *assign;
   unsigned *hist, *gtot, *count, *start;
-  int *order;
+  float *xb;        // the slices regrouped by cluster, stable: bucket position q holds a row at xb + q*sp (sp = s rounded up to even)
   float *cout;
   const float *x;   // row r's slice = x + r*ld + from
+  const float *rcp; // rcp[i] = RN(1 / (i + 1)): the running mean's divisors (update_chains)
+  int *corder;      // clusters by descending size (the longest chains are dispatched first); null: cluster order
   int ld, from, s;
 };
 
@@ -34,7 +36,8 @@ struct KmeansWorkspace {
   DevBuf<unsigned> ties, local, block_tot;
   DevBuf<unsigned long long> tie_total, block_off;
   DevBuf<unsigned> hist, gtot, count, start, mismatch;
-  DevBuf<int> order;                   // rows grouped by cluster, stable (row order inside a cluster)
+  DevBuf<float> xb;                    // row slices grouped by cluster, stable (row order inside a cluster)
+  DevBuf<int> corder;                  // clusters by descending size
   DevBuf<UpdDesc> descs;
   // MFMA filter
   DevBuf<float> apack, offp;

@@ -134,6 +134,11 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
                            int32_t max_iterations, int32_t seed, float *c_out,
                            gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports);
 
+/* Self-test of the running mean's division (kmeans.hip, update_chains): the three-operation quotient
+ * q0 = RN(a y), r = fma(-n, q0, a), q = fma(r, y, q0) with y = RN(1/n) against the correctly rounded division
+ * for every divisor n in [1, n_max] (n_max < 2^24) and `numerators_per_divisor` numerators each (random, and
+ * next to rounding boundaries).  *mismatches must come back 0. */
+int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed, int64_t *mismatches);
 /* Stage times of the training loop for bench.py's k-means record (BASELINE config 3): while enabled, every
  * stage of KMeans.computeClusters / ProductQuantizer.apply is closed by a device synchronisation and its wall
  * time accumulated over the iterations (process-wide; not for concurrent trainings):

@@ -177,3 +177,12 @@ def test_streaming_mfma_assign_bit_exact(oracle, g, n, d, frm, s, k, seed):
         assert np.array_equal(fn(v), oracle.kmeans_assign(X, frm, s, C0, rb))
     it = km.iterate(v, 2)
     assert np.array_equal(bits(it.centroids), bits(oracle.kmeans_iterate(X, frm, s, C0, 2)))
+
+
+def test_mean_division_identity_holds_for_every_divisor(g):
+    """update_chains computes (x - c)/n as q0 = RN(a y), r = fma(-n, q0, a), q = fma(r, y, q0), y = RN(1/n): that must
+    be THE correctly rounded quotient (KMeans.scala:218, the JVM's float division) for every n a cluster can reach."""
+    import ctypes as C
+    bad = C.c_int64(-1)
+    g.native.check(g.native.lib().gulon_selftest_mean_division((1 << 24) - 1, 96, 12345, C.byref(bad)))
+    assert bad.value == 0
