@@ -21,6 +21,8 @@
 // -2*c A operands and the offsets (C-init) sit in LDS.  After the K loop two 32x32 tiles
 // are exchanged with v_permlane32_swap so that each lane owns ONE data row and sees its
 // 32 distances of the centroid block in ascending centroid order.
+#include <type_traits>
+
 #include "kmeans.hpp"
 
 namespace gulon {
@@ -116,10 +118,16 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
     float mband = INFINITY;    // smallest |key - running minimum| seen by this row's scan
     int best = -1;
 
-    // one centroid block = 2*T MFMAs (tiles X and Y), C-init = offsets
-    auto mfma_block = [&](int kb, f32x16 &ax, f32x16 &ay) {
-      // C-init = offsets.  The two accumulator tiles are initialised by two separate LDS reads
-      // (sOff is stored twice) instead of 32 register copies of one read.
+    // One centroid block = 2*T MFMAs (tiles X and Y, C-init = offsets) and one scan epilogue of ~150 VALU
+    // instructions.  A wave issues in order, so ten MFMAs followed by the scan leave the matrix pipe idle for the
+    // whole scan (and two waves of a SIMD fall into lockstep: both in their MFMAs, then both in their scans --
+    // 42 % matrix utilisation in round 1).  The MFMAs of block kb+1 are therefore issued one at a time BETWEEN the
+    // eight pieces of the scan of block kb, pinned there with scheduling barriers: every MFMA's 64 cycles are
+    // covered by ~16 VALU instructions of the same wave.
+    //
+    // C-init: the two accumulator tiles are initialised by two separate LDS reads (sOff is stored twice) instead
+    // of 32 register copies of one read.
+    auto init_block = [&](int kb, f32x16 &ax, f32x16 &ay, float (&a)[T]) {
       const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 4 * half);
       const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 4 * half);
 #pragma unroll
@@ -131,38 +139,39 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
       }
       const float *pa = sA + (size_t)kb * T * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < T; t++) {
-        float a = pa[t * 64];
-        ax = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bx[t], ax, 0, 0, 0);
-        ay = __builtin_amdgcn_mfma_f32_32x32x2f32(a, by[t], ay, 0, 0, 0);
-      }
+      for (int t = 0; t < T; t++) a[t] = pa[t * 64];
     };
-
-    // scan epilogue of one centroid block held in (ax, ay)
-    auto scan_block = [&](int kb, f32x16 &ax, f32x16 &ay) {
-      // lanes 0-31 end up with tile X's row (lane), lanes 32-63 with tile Y's row (lane-32):
-      // ax[r] = centroids 8(r>>2) + (r&3), ay[r] = centroids 8(r>>2) + 4 + (r&3) of this block
+    // MFMA number m of a block: t = m / 2, tile X (even m) or Y (odd m)
+    auto one_mfma = [&](int m, f32x16 &ax, f32x16 &ay, const float (&a)[T]) {
+      if (m & 1) ay = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 1], by[m >> 1], ay, 0, 0, 0);
+      else ax = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 1], bx[m >> 1], ax, 0, 0, 0);
+    };
+    // Piece h (0..7) of the scan epilogue of the block held in (ax, ay): centroids 4h .. 4h+3 of the block.
+    // After the swaps lanes 0-31 hold tile X's row (lane), lanes 32-63 tile Y's row (lane-32):
+    // ax[r] = centroids 8(r>>2) + (r&3), ay[r] = centroids 8(r>>2) + 4 + (r&3) of this block.
+    // The reference's scan over c on d' (ascending centroid index), in 3.5 VALU ops per distance: the position j
+    // inside the block replaces the 5 low mantissa bits of d' ("key"), so ONE running float minimum carries both
+    // the value and the winner; the band test accumulates  min |key_j - running_min_before_j|  with a 3-input min
+    // and is compared once per row.  The <= 31 ulp key perturbation is part of the band (errk).
+    auto scan_piece = [&](int h, f32x16 &ax, f32x16 &ay) {
+      if ((h & 1) == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
-        ax[r] = __uint_as_float(sw[0]);
-        ay[r] = __uint_as_float(sw[1]);
+        for (int r = 4 * (h >> 1); r < 4 * (h >> 1) + 4; r++) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
+          ax[r] = __uint_as_float(sw[0]);
+          ay[r] = __uint_as_float(sw[1]);
+        }
       }
-      // The reference's scan over c on d' (ascending centroid index), in 3.5 VALU ops per
-      // distance.  The position j inside the block replaces the 5 low mantissa bits of d'
-      // ("key"), so ONE running float minimum carries both the value and the winner; the
-      // band test accumulates  min |key_j - running_min_before_j|  with a 3-input min and is
-      // compared once per row.  The <= 31 ulp key perturbation is part of the band (errk).
-      unsigned key[32];
+      unsigned key[4];
 #pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const float v = ((j >> 2) & 1) ? ay[4 * (j >> 3) + (j & 3)] : ax[4 * (j >> 3) + (j & 3)];
-        key[j] = (__float_as_uint(v) & ~31u) | (unsigned)j;
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * h + e;
+        const float v = (h & 1) ? ay[4 * (h >> 1) + e] : ax[4 * (h >> 1) + e];
+        key[e] = (__float_as_uint(v) & ~31u) | (unsigned)j;
       }
-      const float qbefore = pmin;
 #pragma unroll
-      for (int j = 0; j < 32; j += 2) {
-        const float k0 = __uint_as_float(key[j]), k1 = __uint_as_float(key[j + 1]);
+      for (int e = 0; e < 4; e += 2) {
+        const float k0 = __uint_as_float(key[e]), k1 = __uint_as_float(key[e + 1]);
         float q0, q1;
         // plain v_min_f32 / v_min3_f32: the intrinsic forms add a canonicalising v_max per value
         asm("v_min_f32 %0, %1, %2" : "=v"(q0) : "v"(pmin), "v"(k0));
@@ -171,18 +180,47 @@ __global__ __launch_bounds__(256) void assign_mfma(const float *__restrict__ xq,
         asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
         pmin = q1;
       }
+    };
+    // scan block kb (in sx, sy) while the MFMAs of block kb + 1 go into (nx_, ny_)
+    auto step = [&](auto next_tag, int kb, f32x16 &sx, f32x16 &sy, f32x16 &nx_, f32x16 &ny_) {
+      constexpr bool NEXT = decltype(next_tag)::value;
+      float a[T];
+      if (NEXT) init_block(kb + 1, nx_, ny_, a);
+      const float qbefore = pmin;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        if (NEXT) {
+#pragma unroll
+          for (int m = 0; m < 2 * T; m++)
+            if (m * 8 / (2 * T) == h) one_mfma(m, nx_, ny_, a);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        scan_piece(h, sx, sy);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (__float_as_uint(pmin) != __float_as_uint(qbefore)) best = kb * 32 + (int)(__float_as_uint(pmin) & 31u);
     };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
-    // software pipeline without register copies: two accumulator sets alternate, the matrix
-    // pipe works on block kb+1 while the VALU scans block kb
     f32x16 ax, ay, bx2, by2;
-    mfma_block(0, ax, ay);
-    for (int kb = 0; kb < nkb; kb += 2) {
-      if (kb + 1 < nkb) mfma_block(kb + 1, bx2, by2);
-      scan_block(kb, ax, ay);
-      if (kb + 2 < nkb) mfma_block(kb + 2, ax, ay);
-      if (kb + 1 < nkb) scan_block(kb + 1, bx2, by2);
+    {
+      float a0[T];
+      init_block(0, ax, ay, a0);
+#pragma unroll
+      for (int m = 0; m < 2 * T; m++) one_mfma(m, ax, ay, a0);
+    }
+    int kb = 0;
+    for (; kb + 2 < nkb; kb += 2) {
+      step(Yes{}, kb, ax, ay, bx2, by2);
+      step(Yes{}, kb + 1, bx2, by2, ax, ay);
+    }
+    if (kb + 1 < nkb) {
+      step(Yes{}, kb, ax, ay, bx2, by2);
+      step(No{}, kb + 1, bx2, by2, ax, ay);
+    } else {
+      step(No{}, kb, ax, ay, bx2, by2);
     }
 
     const long long row = pp * 64 + lane;
