@@ -510,6 +510,93 @@ __global__ void peel_finalize(const float *__restrict__ pv, const int *__restric
   if (out_flags) out_flags[q] = flags;
 }
 
+// the peeled list as a partial (K+1)-list for the multi-GPU merge: [B][cap] -> [B][K+1]
+__global__ void peel_export(const float *__restrict__ pv, const int *__restrict__ pi, int B, int cap, int keff,
+                            float *__restrict__ out_v, int *__restrict__ out_i) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * keff) return;
+  const int q = (int)(t / keff), e = (int)(t - (long long)q * keff);
+  out_v[t] = pv[(size_t)q * cap + e];
+  out_i[t] = pi[(size_t)q * cap + e];
+}
+
+// Merge of two ascending (distance, row id) lists of `len` entries per query (padded with (+inf, INT_MAX)) into
+// the `len` smallest, ascending: every entry's position = its own index + its rank in the other list (row ids
+// are distinct across lists, so the order is strict).  b == nullptr: a copies through.
+__global__ __launch_bounds__(256) void merge2_long(const float *__restrict__ av, const int *__restrict__ ai,
+                                                   const float *__restrict__ bv, const int *__restrict__ bi, int len,
+                                                   float *__restrict__ ov, int *__restrict__ oi) {
+  const int q = blockIdx.x;
+  const float *A = av + (size_t)q * len, *Bv = bv ? bv + (size_t)q * len : nullptr;
+  const int *Ai = ai + (size_t)q * len, *Bi = bi ? bi + (size_t)q * len : nullptr;
+  float *O = ov + (size_t)q * len;
+  int *Oi = oi + (size_t)q * len;
+  auto less = [](float v0, int i0, float v1, int i1) { return v0 < v1 || (v0 == v1 && i0 < i1); };
+  for (int e = threadIdx.x; e < len; e += blockDim.x) {
+    if (!Bv) { O[e] = A[e]; Oi[e] = Ai[e]; continue; }
+    {   // A[e]: entries of B before it
+      const float v = A[e]; const int id = Ai[e];
+      int lo = 0, hi = len;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (less(Bv[mid], Bi[mid], v, id)) lo = mid + 1; else hi = mid; }
+      const int pos = e + lo;
+      if (pos < len && id != INT_MAX) { O[pos] = v; Oi[pos] = id; }
+    }
+    {   // B[e]: entries of A before it
+      const float v = Bv[e]; const int id = Bi[e];
+      int lo = 0, hi = len;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (less(A[mid], Ai[mid], v, id)) lo = mid + 1; else hi = mid; }
+      const int pos = e + lo;
+      if (pos < len && id != INT_MAX) { O[pos] = v; Oi[pos] = id; }
+    }
+  }
+}
+__global__ void fill_list(float *__restrict__ v, int *__restrict__ i, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) { v[t] = INFINITY; i[t] = INT_MAX; }
+}
+
+// `lists` partial (K+1)-lists per query (element (l, q, e) at l*stride_l + q*keff + e) -> final [B][K] + count + flags,
+// for K beyond the 63 a wavefront list holds: a tree of pairwise merges through device scratch
+void launch_merge_long(const float *in_v, const int *in_i, int lists, long long stride_l, int B, int K, int *out_idx,
+                       float *out_dist, int *out_count, int *out_flags, hipStream_t st) {
+  const int keff = K + 1;
+  const size_t per = (size_t)B * keff;
+  int width = lists;                       // lists alive in the current round
+  DevBuf<float> va, vb;
+  DevBuf<int> ia, ib;
+  const size_t half = (size_t)((lists + 1) / 2);
+  va.alloc(std::max<size_t>(half * per, 1)); ia.alloc(std::max<size_t>(half * per, 1));
+  vb.alloc(std::max<size_t>(((half + 1) / 2) * per, 1)); ib.alloc(std::max<size_t>(((half + 1) / 2) * per, 1));
+  const float *cv = in_v;
+  const int *ci = in_i;
+  long long cs = stride_l;
+  bool to_a = true;
+  if (width == 1) {   // a single list: straight to the finaliser
+    launch_peel_finalize(cv, ci, B, keff, K, out_idx, out_dist, out_count, out_flags, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    return;
+  }
+  while (width > 1) {
+    const int next = (width + 1) / 2;
+    float *ov = to_a ? va.p : vb.p;
+    int *oi = to_a ? ia.p : ib.p;
+    hipLaunchKernelGGL(fill_list, dim3((unsigned)ceil_div((long long)next * per, 256LL)), dim3(256), 0, st, ov, oi,
+                       (long long)next * per);
+    for (int p = 0; p < next; p++) {
+      const bool pair = 2 * p + 1 < width;
+      hipLaunchKernelGGL(merge2_long, dim3(B), dim3(256), 0, st, cv + (size_t)(2 * p) * cs, ci + (size_t)(2 * p) * cs,
+                         pair ? cv + (size_t)(2 * p + 1) * cs : nullptr, pair ? ci + (size_t)(2 * p + 1) * cs : nullptr, keff,
+                         ov + (size_t)p * per, oi + (size_t)p * per);
+    }
+    HIP_CHECK(hipGetLastError());
+    cv = ov; ci = oi; cs = (long long)per;
+    width = next;
+    to_a = !to_a;
+  }
+  launch_peel_finalize(cv, ci, B, keff, K, out_idx, out_dist, out_count, out_flags, st);
+  HIP_CHECK(hipStreamSynchronize(st));   // the scratch lists above go out of scope
+}
+
 void launch_peel_update(const float *tv, const int *ti, int B, int round, int cap, float *pv, int *pi, float *lbv,
                         int *lbi, hipStream_t st) {
   hipLaunchKernelGGL(peel_update, dim3(B), dim3(64), 0, st, tv, ti, round, cap, pv, pi, lbv, lbi);
@@ -699,8 +786,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
   GULON_REQUIRE(from >= 0 && until <= ix->n, "expected: from >= 0 && until <= length");  // Index.scala:419
   GULON_REQUIRE(K >= 0 && B >= 0, "k and batch size must be non-negative");
   GULON_UNSUPPORTED(K > GULON_MAX_K_PEELED, "k_nn = %d > %d is not supported", K, GULON_MAX_K_PEELED);
-  GULON_UNSUPPORTED(K > GULON_MAX_K && !final_out,
-                    "k_nn = %d > GULON_MAX_K = %d is only supported for unsharded queries", K, GULON_MAX_K);
+  GULON_UNSUPPORTED(K + 1 > GULON_MAX_K_PEELED && !final_out, "k_nn = %d: a shard returns k_nn + 1 <= %d entries", K,
+                    GULON_MAX_K_PEELED);
   if (B == 0) return;
   if (!sb || sb->phase != 2) ix->last_filter_tiles = 0;
   if (sb && sb->phase == 1) {
@@ -733,8 +820,9 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
       if (d_oc) HIP_CHECK(hipMemsetAsync(d_oc, 0, sizeof(int) * (size_t)B, st));
       if (d_of) HIP_CHECK(hipMemsetAsync(d_of, 0, sizeof(int) * (size_t)B, st));
     } else {
-      std::vector<float> inf((size_t)B * keff, INFINITY);
-      std::vector<int> mx((size_t)B * keff, INT_MAX);
+      const int kout = K + 1;   // (peeled queries: keff is the 64-entry round, the partial list K+1 long)
+      std::vector<float> inf((size_t)B * kout, INFINITY);
+      std::vector<int> mx((size_t)B * kout, INT_MAX);
       HIP_CHECK(hipMemcpyAsync(d_pv, inf.data(), sizeof(float) * inf.size(), hipMemcpyHostToDevice, st));
       HIP_CHECK(hipMemcpyAsync(d_pi, mx.data(), sizeof(int) * mx.size(), hipMemcpyHostToDevice, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -755,6 +843,7 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     run_wide_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st);
     return;
   }
+  // the empty-range partial list of a large-K query is [B][K+1], not [B][64]
   const int Bp = ntiles * QT;
   const RbMap all{1, 0, 1};
   if (!peeled && filter_eligible(ix, K, rb_total)) {
@@ -781,8 +870,12 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
       hipLaunchKernelGGL(peel_update, dim3(B), dim3(64), 0, st, ix->peel_tv.p, ix->peel_ti.p, r, cap, ix->peel_v.p,
                          ix->peel_i.p, ix->peel_lbv.p, ix->peel_lbi.p);
     }
-    hipLaunchKernelGGL(peel_finalize, dim3(ceil_div(B, 64)), dim3(64), 0, st, ix->peel_v.p, ix->peel_i.p, B, cap, K,
-                       d_oi, d_od, d_oc, d_of);
+    if (final_out)
+      hipLaunchKernelGGL(peel_finalize, dim3(ceil_div(B, 64)), dim3(64), 0, st, ix->peel_v.p, ix->peel_i.p, B, cap, K,
+                         d_oi, d_od, d_oc, d_of);
+    else   // a shard of a large-K query: its K+1 smallest as a partial list (merged by gulon_topk_merge_dev)
+      hipLaunchKernelGGL(peel_export, dim3((unsigned)ceil_div((long long)B * (K + 1), 256LL)), dim3(256), 0, st,
+                         ix->peel_v.p, ix->peel_i.p, B, cap, K + 1, d_pv, d_pi);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1148,9 +1241,15 @@ GULON_API int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *
                                        float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream) {
   return guarded([&] {
     GULON_REQUIRE(lists >= 1 && b >= 0 && k_nn >= 1, "bad merge shape");
-    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d", k_nn, GULON_MAX_K);
+    GULON_UNSUPPORTED(k_nn + 1 > GULON_MAX_K_PEELED, "k_nn = %d > %d", k_nn, GULON_MAX_K_PEELED - 1);
     int keff = k_nn + 1;
     GULON_REQUIRE(list_stride == 0 || list_stride >= (long long)b * keff, "list_stride too small");
+    if (b == 0) return;
+    if (k_nn > GULON_MAX_K) {   // beyond a wavefront list: pairwise merges through scratch (synchronises the stream)
+      launch_merge_long(d_part_dist, d_part_idx, lists, list_stride ? (long long)list_stride : (long long)b * keff, b, k_nn,
+                        d_out_idx, d_out_dist, d_out_count, d_out_flags, (hipStream_t)stream);
+      return;
+    }
     launch_merge(true, d_part_dist, d_part_idx, lists, list_stride ? (long long)list_stride : (long long)b * keff,
                  (long long)keff, b, k_nn, d_out_idx,
                  d_out_dist, d_out_count, d_out_flags, nullptr, nullptr, (hipStream_t)stream);

@@ -255,7 +255,7 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
   return guarded([&] {
     GULON_REQUIRE(sx != nullptr, "index is null");
     GULON_REQUIRE(b >= 0 && k_nn >= 0, "k and batch size must be non-negative");
-    GULON_UNSUPPORTED(k_nn > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d on a sharded index", k_nn, GULON_MAX_K);
+    GULON_UNSUPPORTED(k_nn + 1 > GULON_MAX_K_PEELED, "k_nn = %d > %d on a sharded index", k_nn, GULON_MAX_K_PEELED - 1);
     if (b == 0) return;
     GULON_REQUIRE(queries != nullptr && (k_nn == 0 || (out_idx != nullptr && out_dist != nullptr)), "null argument");
     if (k_nn == 0) {
@@ -266,6 +266,9 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
     std::lock_guard<std::mutex> lock(sx->mu);
     DeviceGuard guard;
     const int K = k_nn, keff = K + 1, spd = sx->spd, nD = (int)sx->devs.size(), lists = nD * spd;
+    // k_nn beyond a wavefront list (Tests.scala asks for up to 1000 neighbours): every shard peels its K+1 best 64
+    // at a time, the lists are merged pairwise; ties keep the (distance, row id) order and their flags (no replay)
+    const bool large_k = K > GULON_MAX_K;
     const size_t nb = (size_t)b * keff;             // one [B][K+1] array
     const int F0 = GULON_REPLAY_MAX_FLAGGED, C0 = GULON_REPLAY_POOL;
     const size_t words0 = (size_t)gulon_replay_pack_words(F0, C0);
@@ -282,14 +285,16 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
     }
     auto status = [](int32_t rc) { if (rc != GULON_OK) throw DeviceError{rc}; };
     // 1. sample bounds of every shard -> all-gather
-    for (auto &dv : sx->devs) {
-      HIP_CHECK(hipSetDevice(dv.device));
-      for (int s = 0; s < spd; s++) {
-        Slot &sl = dv.slots[s];
-        status(gulon_index_scan_bounds_dev(sl.ix, dv.q.p, b, K, 0, sl.rows, dv.bd_send.p + s * nb, dv.st));
+    if (!large_k) {
+      for (auto &dv : sx->devs) {
+        HIP_CHECK(hipSetDevice(dv.device));
+        for (int s = 0; s < spd; s++) {
+          Slot &sl = dv.slots[s];
+          status(gulon_index_scan_bounds_dev(sl.ix, dv.q.p, b, K, 0, sl.rows, dv.bd_send.p + s * nb, dv.st));
+        }
       }
+      all_gather(sx, [](Dev &dv) { return std::pair<const void *, void *>(dv.bd_send.p, dv.bd_all.p); }, spd * nb, ncclFloat);
     }
-    all_gather(sx, [](Dev &dv) { return std::pair<const void *, void *>(dv.bd_send.p, dv.bd_all.p); }, spd * nb, ncclFloat);
     // 2. the scan against the bound of the union -> all-gather of the packed partial lists -> merge everywhere
     for (auto &dv : sx->devs) {
       HIP_CHECK(hipSetDevice(dv.device));
@@ -302,8 +307,11 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
           HIP_CHECK(hipGetLastError());
           continue;
         }
-        status(gulon_index_scan_partial_bounded_dev(sl.ix, dv.q.p, b, K, 0, sl.rows, dv.bd_all.p, lists,
-                                                    reinterpret_cast<float *>(pk), pk + nb, dv.st));
+        if (large_k)
+          status(gulon_index_scan_partial_dev(sl.ix, dv.q.p, b, K, 0, sl.rows, reinterpret_cast<float *>(pk), pk + nb, dv.st));
+        else
+          status(gulon_index_scan_partial_bounded_dev(sl.ix, dv.q.p, b, K, 0, sl.rows, dv.bd_all.p, lists,
+                                                      reinterpret_cast<float *>(pk), pk + nb, dv.st));
       }
     }
     all_gather(sx, [](Dev &dv) { return std::pair<const void *, void *>(dv.pk_send.p, dv.pk_all.p); }, spd * 2 * nb,
@@ -316,7 +324,7 @@ GULON_API int32_t gulon_sharded_index_batch_query(gulon_sharded_index *sx, const
     // 3. tie-flagged queries: candidate rows of every shard -> all-gather -> literal TopKHeap on every device;
     //    first round sized for the common case, further rounds (after one look at the flag count) until all are done
     int skip = 0, rounds = 0, flagged = 0;
-    for (;;) {
+    while (!large_k) {
       const int F = rounds == 0 ? F0 : F1;
       const size_t words = rounds == 0 ? words0 : words1;
       for (auto &dv : sx->devs) {

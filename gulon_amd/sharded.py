@@ -184,7 +184,8 @@ class ShardedIndex:
             self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
         else:
             pv, pi = self.engine.views(u["pk"], b)
-            if self.share_bounds:
+            large_k = k > N.MAX_K      # beyond a wavefront list: peeled partial lists, long merge, (distance, row) ties
+            if self.share_bounds and not large_k:
                 self.engine.scan_bounds(q, b, k, u["bd"])
                 self._all_gather(u["abd"], u["bd"])
                 self.engine.scan_partial_bounded(q, b, k, u["abd"], self.world, pv, pi)
@@ -192,7 +193,7 @@ class ShardedIndex:
                 self.engine.scan_partial(q, b, k, pv, pi)
             self._all_gather(u["apk"], u["pk"])
             self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
-            if "rp" in u:
+            if "rp" in u and not large_k:
                 # queries with exact distance ties: every shard contributes the rows that may insert into
                 # the reference's heap, the union is replayed identically on every rank (TopKHeap.scala:57-79).
                 # This first round (replay_first queries) is unconditional -- no host synchronisation;

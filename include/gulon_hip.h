@@ -54,8 +54,9 @@ extern "C" {
 
 #define GULON_MAX_K 63 /* neighbours per query held by one wavefront list: fast path, exact tie replay,
                           sharded merge */
-#define GULON_MAX_K_PEELED 8191 /* larger k_nn (unsharded queries, exact kNN): the result is peeled 64
-                                   entries per scan; ties keep the (distance, row id) order + flags */
+#define GULON_MAX_K_PEELED 8191 /* larger k_nn (flat index, sharded or not; exact kNN): the result is peeled 64
+                                   entries per scan (a shard returns k_nn + 1 <= 8191 entries); ties keep the
+                                   (distance, row id) order + flags */
 
 typedef struct gulon_dataset gulon_dataset; /* device-resident Matrix            */
 typedef struct gulon_index gulon_index;     /* device-resident PQIndex (codes+PQ) */
@@ -280,7 +281,8 @@ int32_t gulon_replay_apply_dev(const int32_t *d_packs, int32_t lists, int32_t ma
  * order and tie-flagged queries are replayed with the literal heap over the candidates of all shards, in
  * as many rounds as the batch needs: ids, order, distances and flags equal the unsharded
  * gulon_index_batch_query bit for bit, whatever the number of shards.  codes/cents as gulon_index_create
- * (all n rows); k_nn <= GULON_MAX_K. */
+ * (all n rows).  GULON_MAX_K < k_nn < GULON_MAX_K_PEELED: peeled partial lists, pairwise merge, no tie replay
+ * (as the unsharded index at such k_nn). */
 int32_t gulon_sharded_index_create(const uint8_t *codes, int32_t n, int32_t d, int32_t m, int32_t k,
                                    const float *cents, const int32_t *devices, int32_t n_shards,
                                    gulon_sharded_index **out);
@@ -344,7 +346,8 @@ int32_t gulon_scan_tuning(const char *key, int32_t value);
 /* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
  * the deterministic (distance, row id) order: merges `lists` partial lists per
  * query, laid out [lists][B][K+1], into the final K.  list_stride = elements
- * between consecutive lists (0 = B*(K+1), i.e. dense). */
+ * between consecutive lists (0 = B*(K+1), i.e. dense).  k_nn > GULON_MAX_K (lists from
+ * gulon_index_scan_partial_dev at that k_nn): pairwise merges through scratch; synchronises the stream. */
 int32_t gulon_topk_merge_dev(const float *d_part_dist, const int32_t *d_part_idx, int32_t lists,
                              int64_t list_stride, int32_t b, int32_t k_nn, int32_t *d_out_idx,
                              float *d_out_dist, int32_t *d_out_count, int32_t *d_out_flags, void *stream);

@@ -192,7 +192,29 @@ def test_c_abi_sharded_index_argument_errors(g):
         NodeShardedIndex(pq, enc, [99])
     sx = NodeShardedIndex(pq, enc, [0, 0])
     with pytest.raises(NotImplementedError):
-        sx.batch_query_raw(64, np.zeros((1, 8), np.float32))
+        sx.batch_query_raw(8191, np.zeros((1, 8), np.float32))
     oi, od, oc, of = sx.batch_query_raw(3, np.zeros((0, 8), np.float32))
     assert len(oc) == 0
+    sx.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+@pytest.mark.parametrize("K", [64, 200, 1000])
+def test_c_abi_sharded_index_large_k(oracle, g, devices, K):
+    """Tests.scala asks an index for up to 1000 neighbours: beyond the 63 a wavefront list holds, every shard peels
+    its K+1 best and the lists are merged pairwise -- equal to the unsharded index and (where no distances tie)
+    to the oracle."""
+    from gulon_amd.sharded import NodeShardedIndex
+    n, d, m, k, B = 60000, 32, 8, 256, 5
+    cents, idx, pq, enc = _make(g, n, d, m, k, seed=K)
+    Q = np.random.default_rng(4).standard_normal((B, d)).astype(np.float32)
+    sx = NodeShardedIndex(pq, enc, devices)
+    res = sx.batch_query_raw(K, Q)
+    full = g.PQIndex(pq, enc).batch_query_raw(K, Q)
+    _same(res, full)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    assert np.array_equal(bits(res[1]), bits(od)) and np.array_equal(res[2], oc)
+    for q in range(B):
+        if res[3][q] == 0:
+            assert np.array_equal(res[0][q], oi[q])
     sx.close()

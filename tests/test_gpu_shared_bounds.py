@@ -161,6 +161,15 @@ def test_every_query_flagged_across_shards_is_replayed(oracle, g, tune, world):
     assert np.array_equal(res[0], oi) and np.array_equal(bits(res[1]), bits(od))
 
 
+@pytest.mark.parametrize("K", [64, 300])
+def test_large_k_across_shards(g, tune, K):
+    """k_nn beyond a wavefront list through ShardedIndex (threads as ranks): peeled partial lists, long merge."""
+    n, d, m, k, B = 200000, 32, 8, 256, 7
+    dm, pq, enc = _trained(g, n, d, m, k, seed=3)
+    Q = dm.get_rows(np.arange(B, dtype=np.int32) * 313)
+    _same(sharded_query(g, pq, enc, n, 3, Q, K), g.PQIndex(pq, enc).batch_query_raw(K, Q))
+
+
 @pytest.mark.parametrize("B,K", [(1, 1), (5, 63), (130, 2)])
 def test_shared_bounds_ragged_batches(g, tune, B, K):
     n, d, m, k = 300000, 32, 8, 256
