@@ -703,11 +703,14 @@ void KmeansWorkspace::ensure(int n, int k, int s) {
   local.ensure((size_t)std::max(n, 1));
   tie_total.ensure(1);
   long long nchunks = ceil_div(std::max(n, 1), CHUNK_ROWS);
-  hist.ensure((size_t)nchunks * k);
-  gtot.ensure((size_t)ceil_div(nchunks, SCAN_GROUP) * k);
+  const bool bigk = sizeof(unsigned) * 4 * (size_t)k > 160 * 1024;   // radix path: its scratch lives in the call
+  if (!bigk) {
+    hist.ensure((size_t)nchunks * k);
+    gtot.ensure((size_t)ceil_div(nchunks, SCAN_GROUP) * k);
+  }
   count.ensure(k);
   start.ensure(k);
-  xb.ensure((size_t)std::max(n, 1) * (size_t)((s + 1) & ~1));
+  if (!bigk) xb.ensure((size_t)std::max(n, 1) * (size_t)((s + 1) & ~1));
   corder.ensure(k);
   mismatch.ensure(1);
 }
@@ -842,29 +845,69 @@ void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int 
   if (!j.done) { HIP_CHECK(hipStreamSynchronize(st)); assign_stage3(j); }
 }
 
-// KMeans.fromAssignment for a batch of problems over the same data -> each D.cout (k x s).
-// `d_descs` must hold descs.size() entries of device memory.
-void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st) {
-  const int np = (int)descs.size();
-  if (np == 0) return;
-  if (n <= 0) {
-    for (const UpdDesc &D : descs) HIP_CHECK(hipMemsetAsync(D.cout, 0, sizeof(float) * (size_t)k * D.s, st));
-    return;
+// ---- more clusters than the counting sort's LDS counters hold (k > 10240, up to the 65536 of
+// ProductQuantizer.coderFactory, ProductQuantizer.scala:11-16): the stable order comes from a two-pass LSD radix
+// sort of (row, cluster) pairs -- each pass is the counting sort above with 256 buckets (one byte of the cluster
+// id as the key, the 8-byte pair as the "slice") -- and the chains read their rows through the sorted row ids.
+__global__ void bigk_pairs(const int *__restrict__ assign, int n, int2 *__restrict__ pairs, int *__restrict__ digit) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int a = assign[r];
+  pairs[r] = make_int2(r, a);
+  digit[r] = a & 255;
+}
+__global__ void bigk_digit2(const int2 *__restrict__ pairs, int n, int *__restrict__ digit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) digit[i] = (pairs[i].y >> 8) & 255;
+}
+__global__ void bigk_count(const int *__restrict__ assign, int n, unsigned *__restrict__ count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) atomicAdd(&count[assign[r]], 1u);
+}
+__global__ __launch_bounds__(1024) void bigk_starts(const unsigned *__restrict__ count, int k, unsigned *__restrict__ start) {
+  __shared__ unsigned part[1024];
+  const int per = (k + 1023) / 1024, t = threadIdx.x;
+  unsigned sum = 0;
+  for (int c = t * per; c < min(k, t * per + per); c++) sum += count[c];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) { unsigned run = 0; for (int i = 0; i < 1024; i++) { const unsigned v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  unsigned run = part[t];
+  for (int c = t * per; c < min(k, t * per + per); c++) { start[c] = run; run += count[c]; }
+}
+// one thread per (cluster, dim), rows through the sorted pairs (KMeans.scala:211-224; IEEE division)
+__global__ void update_chains_indirect(const int2 *__restrict__ pairs, const unsigned *__restrict__ count,
+                                       const unsigned *__restrict__ start, const float *__restrict__ X, int ld, int from,
+                                       int s, int k, float *__restrict__ cout) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)k * s) return;
+  const int c = (int)(t / s), j = (int)(t - (long long)c * s);
+  const unsigned len = count[c];
+  const int2 *ord = pairs + start[c];
+  float p = 0.f;
+  constexpr int U = 8;
+  unsigned i = 0;
+  for (; i + U <= len; i += U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) x[u] = X[(size_t)ord[i + u].x * ld + from + j];
+#pragma unroll
+    for (int u = 0; u < U; u++) p = p + __fdiv_rn(x[u] - p, (float)(int)(i + u + 1));
   }
-  HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
-  int smax = 1;
-  for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
+  for (; i < len; i++) p = p + __fdiv_rn(X[(size_t)ord[i].x * ld + from + j] - p, (float)(int)(i + 1));
+  cout[t] = p;
+}
+
+static void launch_counting_sort(UpdDesc *d_descs, int np, int n, int k, int smax, bool compact, hipStream_t st) {
   long long nchunks = ceil_div(n, CHUNK_ROWS);
   long long ngroups = ceil_div(nchunks, SCAN_GROUP);
-  bool compact = true;   // every problem reads a compact copy of its slice (ld == s): the staged placement's coalesced loads
-  for (const UpdDesc &D : descs) compact = compact && D.ld == D.s && D.from == 0;
   const int sp_max = (smax + 1) & ~1;
   const bool staged = compact && k <= 1024 && sp_max <= 16;
   const size_t shm_hist = sizeof(unsigned) * (size_t)k;
   const size_t shm_place = staged ? sizeof(unsigned) * (5 * (size_t)k + CHUNK_ROWS + CHUNK_ROWS / 2 + 2) + sizeof(float) * CHUNK_ROWS * (size_t)sp_max
                                   : sizeof(unsigned) * 4 * (size_t)k;
-  GULON_UNSUPPORTED(shm_place > 160 * 1024, "k-means update with k = %d clusters needs %zu B of LDS for its per-cluster counters "
-                    "(> 160 KiB): train at most 10240 clusters per quantizer on the GPU", k, shm_place);
+  GULON_UNSUPPORTED(shm_place > 160 * 1024, "internal: counting sort with k = %d needs %zu B of LDS", k, shm_place);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm_hist));
   hipLaunchKernelGGL(sort_hist, dim3((unsigned)nchunks, np), dim3(256), shm_hist, st, d_descs, n, k);
@@ -878,6 +921,57 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(place), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm_place));
   hipLaunchKernelGGL(place, dim3((unsigned)nchunks, np), dim3(256), shm_place, st, d_descs, n, k, key_bits);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void kmeans_update_bigk(const UpdDesc &D, UpdDesc *d_desc, int n, int k, hipStream_t st) {
+  // scratch of this rare path lives for the call (synchronised before it goes)
+  DevBuf<int2> p0((size_t)n), p1((size_t)n), p2((size_t)n);
+  DevBuf<int> digit((size_t)n);
+  const long long nchunks = ceil_div(n, CHUNK_ROWS);
+  DevBuf<unsigned> hist((size_t)nchunks * 256), gtot((size_t)ceil_div(nchunks, SCAN_GROUP) * 256), c256(256), s256(256);
+  hipLaunchKernelGGL(bigk_pairs, dim3(ceil_div(n, 256)), dim3(256), 0, st, D.assign, n, p0.p, digit.p);
+  for (int pass = 0; pass < 2; pass++) {
+    UpdDesc S{};
+    S.assign = digit.p; S.hist = hist.p; S.gtot = gtot.p; S.count = c256.p; S.start = s256.p;
+    S.x = reinterpret_cast<const float *>(pass == 0 ? p0.p : p1.p); S.ld = 2; S.from = 0; S.s = 2;
+    S.xb = reinterpret_cast<float *>(pass == 0 ? p1.p : p2.p);
+    S.cout = nullptr; S.rcp = nullptr; S.corder = nullptr;
+    HIP_CHECK(hipMemcpyAsync(d_desc, &S, sizeof(UpdDesc), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));   // S is a stack object
+    launch_counting_sort(d_desc, 1, n, 256, 2, true, st);
+    if (pass == 0) hipLaunchKernelGGL(bigk_digit2, dim3(ceil_div(n, 256)), dim3(256), 0, st, p1.p, n, digit.p);
+  }
+  HIP_CHECK(hipMemsetAsync(D.count, 0, sizeof(unsigned) * (size_t)k, st));
+  hipLaunchKernelGGL(bigk_count, dim3(ceil_div(n, 256)), dim3(256), 0, st, D.assign, n, D.count);
+  hipLaunchKernelGGL(bigk_starts, dim3(1), dim3(1024), 0, st, D.count, k, D.start);
+  hipLaunchKernelGGL(update_chains_indirect, dim3((unsigned)ceil_div((long long)k * D.s, 256LL)), dim3(256), 0, st, p2.p,
+                     D.count, D.start, D.x, D.ld, D.from, D.s, k, D.cout);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// KMeans.fromAssignment for a batch of problems over the same data -> each D.cout (k x s).
+// `d_descs` must hold descs.size() entries of device memory.
+void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st) {
+  const int np = (int)descs.size();
+  if (np == 0) return;
+  if (n <= 0) {
+    for (const UpdDesc &D : descs) HIP_CHECK(hipMemsetAsync(D.cout, 0, sizeof(float) * (size_t)k * D.s, st));
+    return;
+  }
+  if (sizeof(unsigned) * 4 * (size_t)k > 160 * 1024) {   // k > 10240: radix-sorted row ids, one problem at a time
+    GULON_UNSUPPORTED(k > 65536, "too many clusters: %d", k);
+    for (const UpdDesc &D : descs) kmeans_update_bigk(D, d_descs, n, k, st);
+    return;
+  }
+  HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
+  int smax = 1;
+  for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
+  bool compact = true;   // every problem reads a compact copy of its slice (ld == s): the staged placement's coalesced loads
+  for (const UpdDesc &D : descs) compact = compact && D.ld == D.s && D.from == 0;
+  const int sp_max = (smax + 1) & ~1;
+  launch_counting_sort(d_descs, np, n, k, smax, compact, st);
   bool one_stride = true;   // every problem with the same bucket row stride: the chains take it as a constant
   for (const UpdDesc &D : descs) one_stride = one_stride && ((D.s + 1) & ~1) == sp_max;
   auto chains = !one_stride ? update_chains<0> : sp_max == 2 ? update_chains<2> : sp_max == 4 ? update_chains<4>

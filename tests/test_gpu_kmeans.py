@@ -186,3 +186,23 @@ def test_mean_division_identity_holds_for_every_divisor(g):
     bad = C.c_int64(-1)
     g.native.check(g.native.lib().gulon_selftest_mean_division((1 << 24) - 1, 96, 12345, C.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("n,d,frm,s,k", [(60000, 6, 1, 3, 12000), (80000, 4, 0, 4, 40000)])
+def test_more_than_10240_clusters(oracle, g, n, d, frm, s, k):
+    """ProductQuantizer.coderFactory allows up to 65 536 clusters per quantizer (ProductQuantizer.scala:11-16):
+    beyond the counting sort's LDS counters the stable order of fromAssignment (KMeans.scala:198-226) comes from
+    a two-pass radix sort of (row, cluster) pairs."""
+    X = _clustered(k, n, d, kc=16)
+    dm = g.DeviceMatrix.from_host(X)
+    v = g.Vectors(dm, frm, frm + s)
+    km = g.KMeans.init(k, v, 3)
+    C0, _ = oracle.kmeans_init(X, frm, s, k, 3)
+    a = km.par_assign(v)
+    assert np.array_equal(a, oracle.kmeans_assign(X, frm, s, C0, 25000))
+    nxt = g.KMeans.from_assignment(k, s, v, a)
+    assert np.array_equal(bits(nxt.centroids), bits(oracle.kmeans_from_assignment(X, frm, s, k, a)))
+    reps = []
+    trained = g.KMeans.compute_clusters(v, g.KMeansConfig(k, 2, 5, reps.append))
+    Cc, oreps = oracle.kmeans_compute_clusters(X, frm, s, k, 2, 5)
+    assert np.array_equal(bits(trained.centroids), bits(Cc)) and len(reps) == len(oreps)
