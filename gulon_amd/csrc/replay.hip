@@ -173,6 +173,73 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
   }
 }
 
+// The same segment scan over the 16-bit codes of a wide index (k > 256, wide.hip): codes [n/64][m][64], the
+// flagged query's table [m][k] gathered from global memory (L2) -- the reference's j-ordered unfused sum.
+__global__ __launch_bounds__(256) void rp_scan_wide(const uint16_t *__restrict__ codes, int m, int k,
+                                                    const float *__restrict__ tables /*[f][m][k]*/,
+                                                    const int *__restrict__ count, int maxf, int row_from, int row_until,
+                                                    int row_base, int rb_lo, int rb_hi, int rb_per_seg, int nseg, int K,
+                                                    const float *__restrict__ start_v, const int *__restrict__ start_c,
+                                                    float *__restrict__ out_v, int *__restrict__ out_i,
+                                                    int *__restrict__ out_c, int pool, float *__restrict__ evv,
+                                                    int *__restrict__ evi, int *__restrict__ evcnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x * 4 + wave;
+  const int nf = min(*count, maxf);
+  if (s >= nseg) return;
+  for (int f = blockIdx.y; f < nf; f += gridDim.y) {
+    const float *T = tables + (size_t)f * m * k;
+    WaveList wl;
+    wl.init();
+    int cnt = 0;
+    if (start_v) {
+      cnt = start_c[f];
+      if (lane < cnt) { wl.v = start_v[(size_t)f * K + lane]; wl.i = -1; }
+      if (cnt >= K) { wl.tau = readlane_f(wl.v, K - 1); wl.tau_i = -1; }
+    }
+    float pv = 0.f;
+    int pi = 0, npend = 0;
+    auto flush = [&]() {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&evcnt[f], npend);
+      base = readlane_i(base, 0);
+      if (lane < npend && base + lane < pool) {
+        evv[(size_t)f * pool + base + lane] = pv;
+        evi[(size_t)f * pool + base + lane] = pi;
+      }
+      npend = 0;
+    };
+    const int rb0 = rb_lo + s * rb_per_seg;
+    const int rb1 = min(rb_hi, rb0 + rb_per_seg);
+    for (int rb = rb0; rb < rb1; rb++) {
+      const uint16_t *p = codes + (size_t)rb * m * 64 + lane;
+      float acc = 0.f;
+      for (int j = 0; j < m; j++) acc += T[(size_t)j * k + p[(size_t)j * 64]];
+      const int row = rb * 64 + lane;
+      const bool valid = row >= row_from && row < row_until;
+      unsigned long long mk = __ballot(valid && (cnt < K || acc < wl.tau));
+      while (mk) {
+        int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        float cv = readlane_f(acc, l);
+        int cr = rb * 64 + l + row_base;
+        if (cnt < K || cv < wl.tau) {   // TopKHeap.update: not full, or root > v (strict)
+          if (lane == npend) { pv = cv; pi = cr; }
+          if (++npend == 64) flush();
+          wl.insert(cv, cr, K, lane);
+          if (cnt < K) cnt++;
+        }
+      }
+    }
+    if (npend) flush();
+    if (out_v) {
+      const size_t fs = (size_t)f * nseg + s;
+      if (lane < K) { out_v[fs * K + lane] = wl.v; out_i[fs * K + lane] = wl.i; }
+      if (lane == 0) out_c[fs] = cnt;
+    }
+  }
+}
+
 // K smallest distances of (start list) + (the new entries of nseg segment lists); one wave per query.
 __global__ __launch_bounds__(64) void rp_merge(const float *__restrict__ start_v, const int *__restrict__ start_c,
                                                const float *__restrict__ seg_v, const int *__restrict__ seg_i,
@@ -374,10 +441,9 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
 void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
                     int C, int *pack, hipStream_t st, int skip = 0) {
   const Pack pk{pack, F, C};
-  // (wide codes, k > 256: no replay -- an empty pack, the tie flags stay as the merge set them)
-  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, ix->wide ? 0 : B, pk, skip);
+  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, B, pk, skip);
   HIP_CHECK(hipGetLastError());
-  if (until <= from || ix->wide) return;
+  if (until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
   const int gy = std::min(F, 16);   // y extent of the scan grids
   // level geometry (in 64-row blocks)
@@ -388,18 +454,28 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   const int per2 = std::max(RP_L2_MIN, ceil_div(l2, RP_L2_SEGS));
   const int segs2 = ceil_div(l2, per2);
   ix->rp_q.ensure((size_t)F * ix->d);
-  ix->rp_tables.ensure((size_t)F * ix->m_pad * 256);
+  ix->rp_tables.ensure(ix->wide ? (size_t)F * ix->m * ix->k : (size_t)F * ix->m_pad * 256);
   ix->rp_segtop.ensure((size_t)F * std::max(segs1, 1) * K); ix->rp_segi.ensure((size_t)F * std::max(segs1, 1) * K);
   ix->rp_segcnt.ensure((size_t)F * std::max(segs1, 1));
   ix->rp_l0v.ensure((size_t)F * K); ix->rp_l0i.ensure((size_t)F * K); ix->rp_l0c.ensure(F);
   ix->rp_prefix.ensure((size_t)F * K); ix->rp_precnt.ensure(F);
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)F * ix->d, 256)), dim3(256), 0, st, dQ, ix->d, F,
                      pk.list(), pk.count(), ix->rp_q.p);
-  launch_build_tables(1, ix, ix->rp_q.p, F, F, ix->rp_tables.p, st, pk.count());
+  if (ix->wide)   // (tables of all F slots: the flagged-query count stays on the device)
+    launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->rp_q.p, 0, F, ix->rp_tables.p, st);
+  else
+    launch_build_tables(1, ix, ix->rp_q.p, F, F, ix->rp_tables.p, st, pk.count());
   const size_t lds = (size_t)ix->m_pad * 256 * sizeof(float);
   auto scan = [&](int rb_lo, int rb_hi, int per_seg, int nseg, const float *sv, const int *sc, float *ov, int *oi,
                   int *oc) {
     if (nseg <= 0) return;
+    if (ix->wide) {
+      hipLaunchKernelGGL(rp_scan_wide, dim3(ceil_div(nseg, 4), gy), dim3(256), 0, st, ix->wcodes.p, ix->m, ix->k,
+                         ix->rp_tables.p, pk.count(), F, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K, sv, sc,
+                         ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt());
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     auto kern = ix->vec == 16 ? rp_scan<16> : rp_scan<4>;
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -453,13 +529,19 @@ void replay_apply(const int *packs, int lists, long long stride_words, int F, in
 
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
                     int *d_oc, int *d_of, hipStream_t st) {
-  if (B <= 0 || K <= 0 || until <= from || ix->wide) return;
-  const int F = std::min(B, RP_MAXF), C = RP_POOL;
+  if (B <= 0 || K <= 0 || until <= from) return;
+  // wide codes: a flagged query's table is m * k floats in HBM -- at most 256 MiB of them per round, and as many
+  // rounds as the batch could need (the flagged-query count stays on the device: later rounds find nothing to do)
+  int F = std::min(B, RP_MAXF);
+  if (ix->wide) F = (int)std::max<size_t>(1, std::min<size_t>((size_t)F, (256ull << 20) / ((size_t)ix->m * ix->k * sizeof(float))));
+  const int C = RP_POOL;
   ix->rp_pack.ensure(replay_pack_words(F, C));
   unsigned long long *dbgp = nullptr;
   if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
-  replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st);
-  replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st);
+  for (int skip = 0; skip < B; skip += F) {
+    replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st, skip);
+    replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st);
+  }   // (byte codes: F = min(B, 1024) -- one round unless the batch is larger than that)
 }
 
 }  // namespace gulon

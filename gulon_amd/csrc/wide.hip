@@ -15,8 +15,9 @@
 //            slice with the running sums parked in HBM in between; k > 32 768 (one quantizer = 256 KiB)
 //            gathered from L2/HBM; lane = row; every wave keeps its own sorted top-(K+1) list in
 //            registers (WaveList), written out as one partial list per wave;
-//   merge    the common merge_lists of scan.hip (ties flagged; the exact TopKHeap replay of tied
-//            queries is not built for wide codes: their flags come back without GULON_FLAG_EXACT_REPLAY).
+//   merge    the common merge_lists of scan.hip; queries flagged with exact distance ties are then replayed with
+//            the literal TopKHeap like those of a byte-coded index (replay.hip: rp_scan_wide gathers the flagged
+//            query's table from global memory).
 #include "scan.hpp"
 
 namespace gulon {
@@ -182,6 +183,10 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
   ix->part_i.ensure((size_t)qb * lists * keff);
   if (passes > 1) ix->wpartial.ensure((size_t)qb * rows_pad);
   int *flags = d_of;
+  if (final_out && replay_enabled() && flags == nullptr) {   // the replay needs the tie flags even if the caller does not
+    ix->flags_scratch.ensure((size_t)B);
+    flags = ix->flags_scratch.p;
+  }
   for (int q0 = 0; q0 < B; q0 += qb) {
     const int nq = std::min(qb, B - q0);
     launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, m, k, dQ, q0, nq, ix->tables.p, st);
@@ -214,6 +219,8 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
                  final_out && d_oc ? d_oc + q0 : nullptr, final_out && flags ? flags + q0 : nullptr,
                  final_out ? nullptr : d_pv + (size_t)q0 * keff, final_out ? nullptr : d_pi + (size_t)q0 * keff, st);
   }
+  // queries with exact distance ties: the reference heap's insertion history (replay.hip, rp_scan_wide)
+  if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
 }
 
 }  // namespace gulon

@@ -50,18 +50,20 @@ def test_wide_query_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
     ix.close()
 
 
-def test_wide_ties_are_flagged_not_replayed(oracle, g):
-    n, d, m, k, B, K = 12000, 16, 4, 1000, 6, 10
-    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=3, dup=2000)
+@pytest.mark.parametrize("n,d,m,k,B,K,dup", [(12000, 16, 4, 1000, 6, 10, 2000), (150000, 32, 8, 4096, 40, 7, 60000),
+                                            (9000, 8, 2, 40000, 5, 5, 3000)])
+def test_wide_ties_are_replayed_exactly(oracle, g, n, d, m, k, B, K, dup):
+    """Duplicate rows => exact distance ties => the literal TopKHeap replay, also over 16-bit codes: ids and order
+    are the reference heap's (TopKHeap.scala:57-79)."""
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=3, dup=dup)
     ix = g.PQIndex(pq, enc)
-    Q = np.stack([ix.decode(r) for r in range(0, 2000, 2000 // B)][:B]).astype(np.float32)
+    Q = np.stack([ix.decode(r) for r in range(0, dup, dup // B)][:B]).astype(np.float32)
     oi, od, oc, of = ix.batch_query_raw(K, Q)
     ei, ed, ec = oracle.pq_batch_query(idx, d, k, cents, Q, K)
     assert np.array_equal(bits(od), bits(ed)) and np.array_equal(oc, ec)
-    assert ((of & 3) != 0).all() and ((of & 4) == 0).all()     # tie flags, no exact replay for wide codes
-    for q in range(B):                                         # same rows up to the order inside tie groups
-        if not (of[q] & 1):
-            assert sorted(oi[q].tolist()) == sorted(ei[q].tolist())
+    assert ((of & 3) != 0).all() and ((of & 4) != 0).all()     # tie flags, and every one of them replayed
+    assert np.array_equal(oi, ei)
+    ix.close()
 
 
 def test_wide_sharded_equals_unsharded(g):
