@@ -34,6 +34,7 @@ struct gulon_grouped_index {
   // scratch (grown on demand under mu)
   DevBuf<float> q_dev, cdist, hv, od;
   DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok, nn_sized, lit_flag;
+  DevBuf<float> wide_tables;       // k > 256: residual tables, one slot per workgroup of gq_group_scan_wide
   int n_empty = 0;                 // groups without rows (the reference's leading empty group, WordVectors.scala:38-39)
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
@@ -720,6 +721,65 @@ __global__ __launch_bounds__(64 * QM_WAVES) void gq_scan_qm(
   }
 }
 
+// ---- one searched group of one query over 16-bit codes (k > 256: Coder.BytePlus, wide.hip) ----------------
+// The residual's table is m * k floats (64 KiB at k = 1024, 4 MiB at k = 65 536): it is built in a slot of
+// global scratch (one slot per workgroup, which walks the (query, group) pairs), and the group's rows go through
+// the LITERAL TopKHeap in row order -- the same heaps, stored in array order, as gq_group_scan<.., true>, so
+// that gq_merge folds them exactly as GroupedIndex.query does (Index.scala:265-282).  Generality over speed.
+__global__ __launch_bounds__(64) void gq_group_scan_wide(const uint16_t *__restrict__ wcodes, int m, int k, int d,
+                                                         const float *__restrict__ pq_cents,
+                                                         const int *__restrict__ from, const int *__restrict__ sdim,
+                                                         const float *__restrict__ gcent, const int *__restrict__ bounds,
+                                                         const float *__restrict__ Q, const int *__restrict__ nn,
+                                                         int nn_stride, const int *__restrict__ nn_cnt, int stride, int B,
+                                                         int K, float *__restrict__ scratch /*[gridDim.x][m][k]*/,
+                                                         int *__restrict__ hk, float *__restrict__ hv, int *__restrict__ hs) {
+  extern __shared__ float gw_res[];   // d
+  const int lane = threadIdx.x;
+  float *T = scratch + (size_t)blockIdx.x * m * k;
+  const long long pairs = (long long)B * stride;
+  for (long long pr = blockIdx.x; pr < pairs; pr += gridDim.x) {
+    const int q = (int)(pr / stride), t = (int)(pr - (long long)q * stride);
+    if (t >= nn_cnt[q]) continue;
+    const int c = nn[(size_t)q * nn_stride + t];
+    for (int e = lane; e < d; e += 64) gw_res[e] = Q[(size_t)q * d + e] - gcent[(size_t)c * d + e];   // MathUtils.subtract
+    // Index.prepareQuery on the residual (Index.scala:352-383): e ascending, unfused
+    for (int j = 0; j < m; j++) {
+      const int fr = from[j], sj = sdim[j];
+      for (int cc = lane; cc < k; cc += 64) {
+        const float *cent = pq_cents + (size_t)k * fr + (size_t)cc * sj;
+        float acc = 0.f;
+        for (int x = 0; x < sj; x++) {
+          const float dd = gw_res[fr + x] - cent[x];
+          acc += dd * dd;
+        }
+        T[(size_t)j * k + cc] = acc;
+      }
+    }
+    __threadfence();   // the table is read back by other lanes through the vector L1
+    const int row_from = bounds[c], row_until = bounds[c + 1];
+    RegHeap h(K, lane);
+    for (int rb = row_from / 64; rb < (row_until + 63) / 64; rb++) {
+      const uint16_t *p = wcodes + (size_t)rb * m * 64 + lane;
+      float acc = 0.f;                 // PQIndex.distances: j ascending, unfused fp32
+      for (int j = 0; j < m; j++) acc += T[(size_t)j * k + p[(size_t)j * 64]];
+      const int row = rb * 64 + lane;
+      const bool valid = row >= row_from && row < row_until;
+      unsigned long long mk = __ballot(valid && (h.size < K || h.val(0) > acc));
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float x = readlane_f(acc, l);
+        if (h.would_insert(x)) h.update(rb * 64 + l, x);
+      }
+    }
+    const size_t o = ((size_t)q * stride + t) * K;
+    if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
+    if (lane == 0) hs[(size_t)q * stride + t] = h.size;
+    __threadfence();   // the next pair overwrites the table slot
+  }
+}
+
 // ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
 __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
                                                const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
@@ -885,6 +945,25 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   }
   HIP_CHECK(hipGetLastError());
   const int keff = K + 1;
+  if (ix->wide) {
+    // 16-bit codes: the literal heaps for every (query, group) pair, residual tables in global scratch (<= 1 GiB)
+    gx->hk.ensure((size_t)B * stride * K);
+    gx->hv.ensure((size_t)B * stride * K);
+    gx->hs.ensure((size_t)B * stride);
+    const size_t slot = (size_t)ix->m * ix->k * sizeof(float);
+    const long long pairs = (long long)B * stride;
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(pairs, 4096),
+                                                                      std::max<long long>(64, (1ll << 30) / (long long)slot)));
+    gx->wide_tables.ensure((size_t)blocks * ix->m * ix->k);
+    HIP_CHECK(hipMemsetAsync(gx->hs.p, 0, sizeof(int) * (size_t)B * stride, st));
+    hipLaunchKernelGGL(gq_group_scan_wide, dim3(blocks), dim3(64), sizeof(float) * (size_t)ix->d, st, ix->wcodes.p, ix->m,
+                       ix->k, ix->d, ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride,
+                       gx->nn_cnt.p, stride, B, K, gx->wide_tables.p, gx->hk.p, gx->hv.p, gx->hs.p);
+    hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+                       d_od, d_oc, (const int *)nullptr, (const int *)nullptr);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const bool literal_only = getenv("GULON_GROUPED_LITERAL") != nullptr;   // testing aid: literal kernels for every query
   gx->hk.ensure((size_t)B * stride * keff);
   gx->hv.ensure((size_t)B * stride * keff);
@@ -1028,7 +1107,6 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
     GULON_REQUIRE(out != nullptr, "out is null");
     *out = nullptr;
     GULON_REQUIRE(g >= 1 && group_centroids != nullptr && (g == 1 || offsets != nullptr), "bad grouping");
-    GULON_UNSUPPORTED(k > 256, "k = %d > 256 (code widths 10/12/16) is not supported by the grouped index", k);
     // GroupedIndex asserts centroids.length == offsets.length + 1 (Index.scala:240-241); offsets ascend
     std::vector<int> bounds((size_t)g + 1);
     bounds[0] = 0;

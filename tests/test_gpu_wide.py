@@ -99,13 +99,26 @@ def test_pq_train_encode_query_wide_end_to_end(oracle, g):
     _check(oracle, res, oi, od, oc)
 
 
-def test_grouped_index_rejects_wide_codes(g):
-    n, d, m, k = 3000, 8, 2, 300
-    rng = np.random.default_rng(1)
-    X = rng.standard_normal((n, d)).astype(np.float32)
+@pytest.mark.parametrize("k,strategy,limit", [(300, "groups", 2), (1024, "groups", 5), (300, "vectors", 700), (5000, "groups", 3)])
+def test_grouped_index_over_wide_codes(oracle, g, k, strategy, limit):
+    """GroupedIndex with more than 256 centroids per residual quantizer (Coder.BytePlus codes): per-group literal
+    TopKHeaps over 16-bit codes, folded with TopKHeap.merge -- ids, order and distances equal the oracle's."""
+    n, d, m, groups, B, K = 6000, 8, 2, 6, 7, 6
+    rng = np.random.default_rng(k)
+    X = (rng.standard_normal((n, d)) + 3.0 * rng.integers(0, 3, (n, 1))).astype(np.float32)
+    X[-500:] = X[:500]                                           # ties inside and across groups
     dm = g.DeviceMatrix.from_host(X)
-    coarse = g.KMeans.compute_clusters(g.Vectors(dm), g.KMeansConfig(4, 2))
+    coarse = g.KMeans.compute_clusters(g.Vectors(dm), g.KMeansConfig(groups, 2))
     gv = g.group(dm, coarse)
-    pq = g.ProductQuantizer.from_flat(k, d, m, rng.standard_normal(k * d).astype(np.float32))
-    with pytest.raises(NotImplementedError):
-        g.Index.grouped(gv, pq, g.LimitGroups(2))
+    pq = g.ProductQuantizer.apply(gv.residuals, g.ProductQuantizerConfig(k, m, 1))
+    strat = g.LimitGroups(limit) if strategy == "groups" else g.LimitVectors(limit)
+    index = g.Index.grouped(gv, pq, strat)
+    Q = np.concatenate([X[rng.integers(0, n, B - 1)], rng.standard_normal((1, d)).astype(np.float32)])
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), gv.centroids, gv.offsets, Q, K,
+                                      0 if strategy == "groups" else 1, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
+    index.close()
