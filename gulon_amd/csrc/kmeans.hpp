@@ -8,9 +8,14 @@ namespace gulon {
 
 // MFMA-ready copy of the column slice X[:, from:from+s]: [ceil(n/64)*2][T][64] floats,
 // element (tile, t, l) = X[tile*32 + (l&31)][from + 2t + (l>>5)]  (kmeans_mfma.hip)
+// split = true (s <= 16, k <= 576): every element as THREE bf16 pieces x = x1 + x2 + x3 (exact), in the operand order of
+// v_mfma_f32_32x32x16_bf16: xq as uint4 [ceil(n/64)*2][3][64], lane l = row tile*32 + (l & 31), elements 8 (l >> 5) .. +7
+// of the slice; xn[row] = |x|^2 (sequential fp32), the scale of the error band.
 struct PackedSlice {
   DevBuf<float> xq;
+  DevBuf<float> xn;
   int n = 0, from = 0, s = 0, T = 0;
+  bool split = false;
 };
 
 // one problem of a batched KMeans.fromAssignment (kmeans.hip)

@@ -367,6 +367,270 @@ __global__ __launch_bounds__(256) void assign_mfma_stream(const float *__restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same filter on the bf16 matrix cores (s <= 16, k <= 576).
+//
+// v_mfma_f32_32x32x2_f32 runs on the vector ALUs' fp32 rate and does not overlap with VALU work (matrix busy 46 %
+// + vector busy 54 % of the launch in round 1, unchanged by interleaving the instruction streams): five of them per
+// 32 x 32 tile plus ~130 VALU instructions of scan epilogue capped the kernel at ~45 % of the fp32 matrix peak.
+// The bf16 cores are a separate pipe (scripts/micro/bf16_mfma.hip: 12 MFMAs + 144 VALU per iteration take 5.45 ms
+// interleaved against 3.48 + 4.06 alone).  An fp32 value is the exact sum of three bf16 pieces (8 + 8 + 8
+// significand bits, round-to-nearest splitting), so
+//     (-2 c) . x  =  sum over pieces (a, b) of  c_a . x_b ,
+// and the six products with a + b <= 4 carry everything down to 2^-23 of |c||x| -- one v_mfma_f32_32x32x16_bf16
+// each (K = 16 covers the whole sub-vector), fp32 accumulation, C-init = offsets.  The value d' differs from the
+// reference's unfused fp32 chain by at most
+//     E = [ (s + 1) 2^-24 (reference chain)  +  6 (s + 2) 2^-24 (six accumulations of <= s + 1 terms each)
+//           +  2^-22.9 (dropped pieces) ] * (|c|^2 + 2 |x||c|),
+// and the scan epilogue, the band test (2E plus the 31-ulp key perturbation) and the flagged-row protocol are
+// those of assign_mfma<T>: rows with any comparison inside the band go to the exact kernel, so the output is
+// bit-identical to the reference whatever the matrix cores round like (gulon_selftest_assign_band measures the
+// band's margin on the hardware).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float f) {   // round to nearest even; finite inputs
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+// x = p1 + p2 + p3 exactly (each a bf16): p1 = RN(x), p2 = RN(x - p1), p3 = x - p1 - p2
+__device__ __forceinline__ void split3(float x, unsigned &p1, unsigned &p2, unsigned &p3) {
+  p1 = bf16_rn_bits(x);
+  const float r1 = x - bf16_bits_to_f32(p1);
+  p2 = bf16_rn_bits(r1);
+  const float r2 = r1 - bf16_bits_to_f32(p2);
+  p3 = bf16_rn_bits(r2);
+}
+__device__ __forceinline__ void pack8(const float (&v)[8], uint4 &o1, uint4 &o2, uint4 &o3) {
+  unsigned a[8], b[8], c[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) split3(v[e], a[e], b[e], c[e]);
+  o1 = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
+  o2 = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+  o3 = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+}
+
+// rows -> three bf16 operand pieces per (tile, lane) + |x|^2 per row
+__global__ void pack_slice_split(const float *__restrict__ X, int n, int ld, int from, int s, long long nlanes,
+                                 uint4 *__restrict__ out, float *__restrict__ xn) {
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 >= nlanes) return;
+  const int l = (int)(t0 & 63);
+  const long long tile = t0 >> 6;
+  const long long row = tile * 32 + (l & 31);
+  const int e0 = 8 * (l >> 5);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (row < n && e0 + e < s) ? X[(size_t)row * ld + from + e0 + e] : 0.f;
+  uint4 o1, o2, o3;
+  pack8(v, o1, o2, o3);
+  out[(tile * 3 + 0) * 64 + l] = o1;
+  out[(tile * 3 + 1) * 64 + l] = o2;
+  out[(tile * 3 + 2) * 64 + l] = o3;
+  if (l < 32 && row < n) {
+    float acc = 0.f;
+    for (int e = 0; e < s; e++) { const float x = X[(size_t)row * ld + from + e]; acc += x * x; }
+    xn[row] = acc;
+  }
+}
+
+// A operands: -2 c in three bf16 pieces [kb][piece][64 lanes]; offsets (1e38 beyond k) and max |c|^2 as before
+__global__ void pack_centroids_split(const float *__restrict__ C, const float *__restrict__ off, int k, int s, int nkb,
+                                     uint4 *__restrict__ apack, float *__restrict__ offp,
+                                     unsigned *__restrict__ cmax2_bits) {
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 < nkb * 64) {
+    const int l = t0 & 63, kb = t0 >> 6;
+    const int c = kb * 32 + (l & 31), e0 = 8 * (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (c < k && e0 + e < s) ? -2.0f * C[(size_t)c * s + e0 + e] : 0.f;
+    uint4 o1, o2, o3;
+    pack8(v, o1, o2, o3);
+    apack[(kb * 3 + 0) * 64 + l] = o1;
+    apack[(kb * 3 + 1) * 64 + l] = o2;
+    apack[(kb * 3 + 2) * 64 + l] = o3;
+  }
+  if (t0 < nkb * 32) {
+    float o = t0 < k ? off[t0] : 1.0e38f;
+    offp[t0] = o;
+    if (t0 < k && o == o && o < INFINITY) atomicMax(cmax2_bits, __float_as_uint(o));
+  }
+}
+
+// probe != nullptr (one workgroup, selftest): the raw d' of the first tile pair against centroid block 0 go to
+// probe[64 rows][32 centroids] and nothing else is written
+__global__ __launch_bounds__(256) void assign_bf16(const uint4 *__restrict__ xq, const float *__restrict__ xn, int n,
+                                                   long long npairs, const uint4 *__restrict__ apack,
+                                                   const float *__restrict__ offp, int nkb,
+                                                   const unsigned *__restrict__ cmax2_bits, float errk,
+                                                   int *__restrict__ assign, int *__restrict__ flag_rows,
+                                                   unsigned *__restrict__ flag_count, float *__restrict__ probe) {
+  extern __shared__ float sm[];
+  uint4 *sA = reinterpret_cast<uint4 *>(sm);                       // [nkb][3][64]
+  float *sOff = sm + (size_t)nkb * 3 * 64 * 4;                     // 2 copies of nkb*32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < nkb * 3 * 64; e += 256) sA[e] = apack[e];
+  for (int e = tid; e < nkb * 32; e += 256) { sOff[e] = offp[e]; sOff[nkb * 32 + e] = offp[e]; }
+  __syncthreads();
+  const float cmax2 = __uint_as_float(*cmax2_bits);
+  const int half = lane >> 5;
+
+  // B operands of the NEXT tile pair are loaded while the current one is in the matrix pipe
+  const long long pstride = (long long)gridDim.x * 4;
+  uint4 nb[2][3];
+  float nxn;
+  auto load_pair = [&](long long pp) {
+    const long long pc = min(pp, npairs - 1);                      // clamped: always valid
+    const uint4 *px = xq + (size_t)(2 * pc) * 3 * 64 + lane;
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) nb[y][p] = px[(size_t)(y * 3 + p) * 64];
+    const long long row = pc * 64 + lane;
+    nxn = row < n ? xn[row] : 0.f;
+  };
+  load_pair((long long)blockIdx.x * 4 + wave);
+  for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += pstride) {
+    bf16x8 bx[3], by[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) { bx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); by[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
+    const float nx = nxn;            // |x|^2 of the row this lane owns after the swaps (row pp*64 + lane)
+    load_pair(pp + pstride);
+    // 2E band (see file header); non-finite inputs make it NaN => row flagged below
+    const float e2 = errk * (cmax2 + 2.0f * __fsqrt_rn(nx * cmax2)) + 1e-30f;
+
+    float pmin = FLT_MAX;      // running minimum key
+    float mband = INFINITY;    // smallest |key - running minimum| seen by this row's scan
+    int best = -1;
+
+    auto init_block = [&](int kb, f32x16 &ax, f32x16 &ay, bf16x8 (&a)[3]) {
+      const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 4 * half);
+      const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 4 * half);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float4 o = so[2 * g];   // centroids 8g + 4*half + (0..3)
+        ax[4 * g + 0] = o.x; ax[4 * g + 1] = o.y; ax[4 * g + 2] = o.z; ax[4 * g + 3] = o.w;
+        float4 o2 = so2[2 * g];
+        ay[4 * g + 0] = o2.x; ay[4 * g + 1] = o2.y; ay[4 * g + 2] = o2.z; ay[4 * g + 3] = o2.w;
+      }
+#pragma unroll
+      for (int p = 0; p < 3; p++) a[p] = __builtin_bit_cast(bf16x8, sA[(kb * 3 + p) * 64 + lane]);
+    };
+    // the six piece products, smallest first: (a3,b1) (a1,b3) (a2,b2) (a2,b1) (a1,b2) (a1,b1); MFMA m: product m / 2,
+    // tile X (even m) or Y (odd m)
+    auto one_mfma = [&](int m, f32x16 &ax, f32x16 &ay, const bf16x8 (&a)[3]) {
+      constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+      const int t = m >> 1;
+      if (m & 1) ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], by[pb[t]], ay, 0, 0, 0);
+      else ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], bx[pb[t]], ax, 0, 0, 0);
+    };
+    // piece h (0..7) of the scan epilogue: see assign_mfma<T>
+    auto scan_piece = [&](int h, f32x16 &ax, f32x16 &ay) {
+      if ((h & 1) == 0) {
+#pragma unroll
+        for (int r = 4 * (h >> 1); r < 4 * (h >> 1) + 4; r++) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
+          ax[r] = __uint_as_float(sw[0]);
+          ay[r] = __uint_as_float(sw[1]);
+        }
+      }
+      unsigned key[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * h + e;
+        const float v = (h & 1) ? ay[4 * (h >> 1) + e] : ax[4 * (h >> 1) + e];
+        key[e] = (__float_as_uint(v) & ~31u) | (unsigned)j;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const float k0 = __uint_as_float(key[e]), k1 = __uint_as_float(key[e + 1]);
+        float q0, q1;
+        asm("v_min_f32 %0, %1, %2" : "=v"(q0) : "v"(pmin), "v"(k0));
+        asm("v_min_f32 %0, %1, %2" : "=v"(q1) : "v"(q0), "v"(k1));
+        const float d0 = k0 - pmin, d1 = k1 - q0;
+        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
+        pmin = q1;
+      }
+    };
+    auto step = [&](auto next_tag, int kb, f32x16 &sx, f32x16 &sy, f32x16 &nx_, f32x16 &ny_) {
+      constexpr bool NEXT = decltype(next_tag)::value;
+      bf16x8 a[3];
+      if (NEXT) init_block(kb + 1, nx_, ny_, a);
+      const float qbefore = pmin;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        if (NEXT) {
+#pragma unroll
+          for (int m = 0; m < 12; m++)
+            if (m * 8 / 12 == h) one_mfma(m, nx_, ny_, a);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        scan_piece(h, sx, sy);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (__float_as_uint(pmin) != __float_as_uint(qbefore)) best = kb * 32 + (int)(__float_as_uint(pmin) & 31u);
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+
+    f32x16 ax, ay, bx2, by2;
+    {
+      bf16x8 a0[3];
+      init_block(0, ax, ay, a0);
+#pragma unroll
+      for (int m = 0; m < 12; m++) one_mfma(m, ax, ay, a0);
+    }
+    if (probe) {   // selftest: raw distances of (first 64 rows) x (centroid block 0), before any swap
+      if (blockIdx.x == 0 && wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+          probe[(size_t)(lane & 31) * 32 + c] = ax[r];
+          probe[(size_t)(32 + (lane & 31)) * 32 + c] = ay[r];
+        }
+      }
+      return;
+    }
+    int kb = 0;
+    for (; kb + 2 < nkb; kb += 2) {
+      step(Yes{}, kb, ax, ay, bx2, by2);
+      step(Yes{}, kb + 1, bx2, by2, ax, ay);
+    }
+    if (kb + 1 < nkb) {
+      step(Yes{}, kb, ax, ay, bx2, by2);
+      step(No{}, kb + 1, bx2, by2, ax, ay);
+    } else {
+      step(No{}, kb, ax, ay, bx2, by2);
+    }
+
+    const long long row = pp * 64 + lane;
+    const bool in_range = row < n;
+    const bool my_amb = !(mband > e2);   // also true when mband is NaN
+    const bool flagged = in_range && (my_amb || best < 0 || !(e2 < INFINITY) || !(fabsf(pmin) < INFINITY));
+    if (in_range && !flagged) assign[row] = best;
+    const unsigned long long fm = __ballot(flagged);
+    if (fm) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(flag_count, (unsigned)__popcll(fm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (flagged) flag_rows[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)row;
+    }
+  }
+}
+
+static bool mfma_split(int s, int k) {
+  static const bool off = getenv("GULON_KMEANS_F32_MFMA") != nullptr;   // A/B knob: the fp32 matrix instruction instead
+  const int nkb = (k + 31) / 32;
+  return !off && s >= 1 && s <= 16 && ((size_t)nkb * (3 * 64 * 16 + 64 * 4)) <= 60 * 1024;
+}
+static float split_errk(int s) {
+  // band = 2.1 * E + key perturbation (see the kernel's header): E / S = [(s+1) + 6 (s+2)] 2^-24 + 2^-22.9
+  return 2.1f * ((float)(7 * s + 13) * 5.9604645e-8f + 1.28e-7f) + 2.1f * 31.0f * 1.1920929e-7f;
+}
+
 // K-steps of the kernel that handles (s, k): the resident-A kernel when all A operands fit LDS and
 // s <= 16, else the streaming kernel with T rounded up to 16 / 32 / 64 (zero padding is exact);
 // 0 = not supported (s > 128)
@@ -395,8 +659,20 @@ bool mfma_assign_supported(int s, int k) {
 
 void pack_slice(const float *dX, int n, int ld, int from, int s, int k, PackedSlice &ps, hipStream_t st) {
   ps.n = n; ps.from = from; ps.s = s; ps.T = mfma_kernel_T(s, k);
+  ps.split = mfma_split(s, k);
   long long ntile = ((long long)n + 31) / 32;
   ntile = (ntile + 1) / 2 * 2;   // whole pairs
+  if (ps.split) {
+    const long long nlanes = ntile * 64;
+    ps.xq.ensure((size_t)std::max<long long>(nlanes * 3 * 4, 4));     // uint4 per (tile, piece, lane)
+    ps.xn.ensure((size_t)std::max<long long>(ntile * 32, 1));
+    GULON_UNSUPPORTED(nlanes >= (1ll << 32), "slice of %lld rows: a dispatch carries fewer than 2^32 work-items", (long long)n);
+    if (n > 0)
+      hipLaunchKernelGGL(pack_slice_split, dim3((unsigned)ceil_div(nlanes, 256LL)), dim3(256), 0, st, dX, n, ld, from, s,
+                         nlanes, reinterpret_cast<uint4 *>(ps.xq.p), ps.xn.p);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   long long total = ntile * ps.T * 64;
   ps.xq.ensure((size_t)std::max<long long>(total, 1));
   GULON_UNSUPPORTED(total >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items", total);
@@ -412,7 +688,27 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
                         hipStream_t st) {
   const int s = ps.s, T = ps.T, n = ps.n;
   const int nkb = (k + 31) / 32;
-  GULON_REQUIRE(T == mfma_kernel_T(s, k), "packed slice was laid out for another kernel (T = %d)", T);
+  GULON_REQUIRE(T == mfma_kernel_T(s, k) && ps.split == mfma_split(s, k), "packed slice was laid out for another kernel (T = %d)", T);
+  if (ps.split) {
+    ws.apack.ensure((size_t)nkb * 3 * 64 * 4);
+    ws.offp.ensure((size_t)nkb * 32);
+    ws.cmax2.ensure(1);
+    ws.flag_rows.ensure((size_t)std::max(n, 1));
+    ws.flag_count.ensure(1);
+    HIP_CHECK(hipMemsetAsync(ws.cmax2.p, 0, sizeof(unsigned), st));
+    HIP_CHECK(hipMemsetAsync(ws.flag_count.p, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(pack_centroids_split, dim3(ceil_div(nkb * 64, 256)), dim3(256), 0, st, dC, ws.off.p, k, s, nkb,
+                       reinterpret_cast<uint4 *>(ws.apack.p), ws.offp.p, ws.cmax2.p);
+    const long long npairs = ((long long)n + 63) / 64;
+    const size_t lds = (size_t)nkb * (3 * 64 * 16 + 64 * 4);
+    int grid = (int)std::min<long long>((npairs + 3) / 4, 256 * 8);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(assign_bf16, dim3(grid), dim3(256), lds, st, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n,
+                       npairs, reinterpret_cast<const uint4 *>(ws.apack.p), ws.offp.p, nkb, ws.cmax2.p, split_errk(s), d_assign,
+                       ws.flag_rows.p, ws.flag_count.p, (float *)nullptr);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   ws.apack.ensure((size_t)nkb * T * 64);
   ws.offp.ensure((size_t)nkb * 32);
   ws.cmax2.ensure(1);
@@ -459,4 +755,66 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
   HIP_CHECK(hipGetLastError());
 }
 
+// Margin of the bf16-split filter's error band on this GPU: 64 random rows x 32 random centroids of sub-dimension s,
+// coordinates ~ scale * U(-1, 1) with a few large outliers; d' from the matrix cores (probe mode of assign_bf16) against
+// the reference's own arithmetic (offsets[c] - 2 * dot, sequential unfused fp32, KMeans.scala:42-47) computed on the
+// host.  Returns max |d' - d| / (band of that row); the filter is sound while this stays below 1/2 (band = 2E).
+double selftest_assign_band(int s, unsigned long long seed, float scale) {
+  GULON_REQUIRE(mfma_split(s, 32), "the bf16-split filter does not take s = %d", s);
+  const int n = 64, k = 32;
+  std::vector<float> X((size_t)n * s), C((size_t)k * s), off(k);
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ULL + 12345;
+  auto rnd = [&]() {
+    z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+    return (float)((double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0);
+  };
+  for (auto &v : X) { v = scale * rnd(); if ((z & 63) == 0) v *= 37.0f; }
+  for (auto &v : C) { v = scale * rnd(); if ((z & 127) == 0) v *= 11.0f; }
+  for (int c = 0; c < k; c++) {          // KMeans.apply offsets (KMeans.scala:170-186): sequential sum of squares
+    float o = 0.f;
+    for (int e = 0; e < s; e++) o += C[(size_t)c * s + e] * C[(size_t)c * s + e];
+    off[c] = o;
+  }
+  DevBuf<float> dX, dC, dOff, probe((size_t)n * k);
+  dX.upload(X.data(), X.size()); dC.upload(C.data(), C.size()); dOff.upload(off.data(), off.size());
+  PackedSlice ps;
+  pack_slice(dX.p, n, s, 0, s, k, ps, nullptr);
+  DevBuf<uint4> ap((size_t)3 * 64);
+  DevBuf<float> offp(32);
+  DevBuf<unsigned> cmax(1), fc(1);
+  DevBuf<int> as(n), fr(n);
+  HIP_CHECK(hipMemset(cmax.p, 0, 4)); HIP_CHECK(hipMemset(fc.p, 0, 4));
+  hipLaunchKernelGGL(pack_centroids_split, dim3(1), dim3(256), 0, 0, dC.p, dOff.p, k, s, 1, ap.p, offp.p, cmax.p);
+  const size_t lds = (size_t)(3 * 64 * 16 + 64 * 4);
+  hipLaunchKernelGGL(assign_bf16, dim3(1), dim3(256), lds, 0, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n, 1ll, ap.p,
+                     offp.p, 1, cmax.p, split_errk(s), as.p, fr.p, fc.p, probe.p);
+  HIP_CHECK(hipGetLastError());
+  std::vector<float> got((size_t)n * k);
+  probe.download(got.data(), got.size());
+  HIP_CHECK(hipDeviceSynchronize());
+  float cmax2 = 0.f;
+  for (int c = 0; c < k; c++) cmax2 = std::max(cmax2, off[c]);
+  double worst = 0.0;
+  for (int r = 0; r < n; r++) {
+    float nx = 0.f;
+    for (int e = 0; e < s; e++) nx += X[(size_t)r * s + e] * X[(size_t)r * s + e];
+    const float band = split_errk(s) * (cmax2 + 2.0f * std::sqrt(nx * cmax2)) + 1e-30f;
+    for (int c = 0; c < k; c++) {
+      volatile float dot = 0.f;          // the reference's chain, unfused
+      for (int e = 0; e < s; e++) { volatile float pr = X[(size_t)r * s + e] * C[(size_t)c * s + e]; dot = dot + pr; }
+      volatile float two = 2 * dot;
+      const float d = off[c] - two;
+      worst = std::max(worst, std::fabs((double)got[(size_t)r * k + c] - (double)d) / (double)band);
+    }
+  }
+  return worst;
+}
+
 }  // namespace gulon
+
+GULON_API int32_t gulon_selftest_assign_band(int32_t s, uint64_t seed, float scale, double *max_error_over_band) {
+  return gulon::guarded([&] {
+    GULON_REQUIRE(max_error_over_band != nullptr && s >= 1 && s <= 16, "bad arguments");
+    *max_error_over_band = gulon::selftest_assign_band(s, seed, scale);
+  });
+}

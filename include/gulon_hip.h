@@ -140,6 +140,11 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
  * for every divisor n in [1, n_max] (n_max < 2^24) and `numerators_per_divisor` numerators each (random, and
  * next to rounding boundaries).  *mismatches must come back 0. */
 int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed, int64_t *mismatches);
+/* Self-test of the bf16-split MFMA filter of KMeans.assign (kmeans_mfma.hip, assign_bf16): largest
+ * |d' - d| / band over 64 random rows x 32 random centroids of sub-dimension s (coordinates ~ scale * U(-1,1) with
+ * outliers), d' = the matrix cores' value, d = the reference's unfused fp32 chain (KMeans.scala:42-47).  The filter
+ * is sound while the result stays below 0.5 (the band is twice the error bound). */
+int32_t gulon_selftest_assign_band(int32_t s, uint64_t seed, float scale, double *max_error_over_band);
 /* Stage times of the training loop for bench.py's k-means record (BASELINE config 3): while enabled, every
  * stage of KMeans.computeClusters / ProductQuantizer.apply is closed by a device synchronisation and its wall
  * time accumulated over the iterations (process-wide; not for concurrent trainings):

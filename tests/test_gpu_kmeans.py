@@ -206,3 +206,16 @@ def test_more_than_10240_clusters(oracle, g, n, d, frm, s, k):
     trained = g.KMeans.compute_clusters(v, g.KMeansConfig(k, 2, 5, reps.append))
     Cc, oreps = oracle.kmeans_compute_clusters(X, frm, s, k, 2, 5)
     assert np.array_equal(bits(trained.centroids), bits(Cc)) and len(reps) == len(oreps)
+
+
+@pytest.mark.parametrize("s", [1, 2, 5, 8, 9, 10, 16])
+def test_bf16_split_filter_error_stays_inside_its_band(g, s):
+    """The bf16-split MFMA filter (three bf16 pieces per fp32 value, six products) may only differ from the reference's
+    fp32 chain (KMeans.scala:42-47) by its proven bound; the band test assumes twice that."""
+    import ctypes as C
+    worst = 0.0
+    for seed, scale in ((1, 1.0), (2, 1e-3), (3, 300.0), (4, 1e6), (5, 1e-12)):
+        r = C.c_double(-1.0)
+        g.native.check(g.native.lib().gulon_selftest_assign_band(s, seed, scale, C.byref(r)))
+        worst = max(worst, r.value)
+    assert 0.0 <= worst < 0.5, worst
