@@ -785,7 +785,7 @@ static void launch_tie_replay(AssignJob &j) {
   hipLaunchKernelGGL(tie_block_scan, dim3(nseg), dim3(1024), 0, j.st, ws.block_tot.p, bps, ws.block_off.p);
   const int *rows = j.filtered ? j.rows : nullptr;
   const int nrows = j.filtered ? j.nrows : n;
-  if ((long long)j.k * j.s >= 16384) {   // long per-row replays: one wave per drawing row
+  if ((long long)j.k * j.s >= 1024) {   // (all but tiny problems) one wave per drawing row: a thread walking k * s products is a long latency chain
     ws.tie_rows.ensure((size_t)std::max(nrows, 1));
     ws.tie_count.ensure(1);
     HIP_CHECK(hipMemsetAsync(ws.tie_count.p, 0, sizeof(unsigned), j.st));
