@@ -35,6 +35,10 @@ struct gulon_grouped_index {
   DevBuf<float> q_dev, cdist, hv, od;
   DevBuf<int> nn, nn_cnt, hk, hs, oi, oc, qlist, qcount, sel_ok, nn_sized, lit_flag;
   DevBuf<float> wide_tables;       // k > 256: residual tables, one slot per workgroup of gq_group_scan_wide
+  // approximate pre-selection (gq_approx_scan): |g + decode(codes_i)|^2 per row, its maximum, per-query tables, lists
+  DevBuf<float> xnorm, ptab, apv, amv;
+  DevBuf<int> api, ami, anan;
+  float xnmax = 0.f;
   int n_empty = 0;                 // groups without rows (the reference's leading empty group, WordVectors.scala:38-39)
   std::mutex mu;
   ~gulon_grouped_index() { if (pq) gulon_index_destroy(pq); }
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
   __syncthreads();
   for (int e = tid; e < n2; e += 256) {
     float v = e < g ? cdist[(size_t)q * g + e] : INFINITY;
-    if (v != v) s_lit = 1;            // a NaN distance: only the literal heap knows what the reference does with it
+    if (v != v) s_lit = 2;            // a NaN distance: only the literal heap knows what the reference does with it
     sv[e] = v != v ? INFINITY : v;    // NaN distances order last
     si[e] = e < g ? e : INT_MAX;
   }
@@ -189,8 +193,11 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
   // (distance, id) order is the reference's heap order only while the entries that decide the answer -- the
   // searched ones and the first one left out -- have pairwise different distances; otherwise gq_literal_groups
   // redoes this query (equal centroid distances are common: the reference's leading empty group repeats a centroid)
+  // level 2: the tie sits AT the cut (or a NaN is around): the searched SET hangs on the heap's order -- redone before
+  // the scan; level 1: only the ORDER of searched groups does, which matters solely to queries whose RESULT is later
+  // redone literally (TopKHeap.merge runs in search order) -- those are redone then
   for (int e = tid; e + 1 < min(cnt + 1, g); e += 256)
-    if (sv[e] == sv[e + 1]) s_lit = 1;
+    if (sv[e] == sv[e + 1]) atomicMax(&s_lit, e + 1 == cnt ? 2 : 1);
   __syncthreads();
   if (tid == 0) lit[q] = s_lit;
 }
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   const unsigned thr = s_prefix;                           // key of the want-th smallest distance
   for (int c = tid; c < g; c += 256) {
     const unsigned key = keyof(c);
-    if (dq[c] != dq[c]) s_lit = 1;                         // NaN distance: literal heap (gq_literal_groups)
+    if (dq[c] != dq[c]) s_lit = 2;                         // NaN distance: literal heap (gq_literal_groups)
     if (key <= thr) {
       const int p = atomicAdd(&s_count, 1);
       if (p < cap) { sv[p] = __uint_as_float(key); si[p] = c; }
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   // equal distances among the searched groups or at the cut (every entry at the threshold was compacted, so a tie
   // there shows as cnt > want): the reference's heap order decides, not (distance, id) -- gq_literal_groups
   for (int e = tid; e + 1 < min(want + 1, cnt); e += 256)
-    if (sv[e] == sv[e + 1]) s_lit = 1;
+    if (sv[e] == sv[e + 1]) atomicMax(&s_lit, e + 1 == want ? 2 : 1);   // levels: see gq_sorted_groups
   __syncthreads();
   if (tid == 0) { nn_cnt[q] = want; ok[q] = 1; lit[q] = s_lit; }
 }
@@ -288,11 +295,17 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
 // and only the scan for centroids the heap would take is spread over the lanes.
 __global__ __launch_bounds__(64) void gq_literal_groups(const float *__restrict__ cdist, int g, int cap,
                                                         const int *__restrict__ bounds, int by_vectors, int limit,
-                                                        const int *__restrict__ lit, int *__restrict__ nn, int stride,
+                                                        const int *__restrict__ lit, int level, const int *__restrict__ qlist,
+                                                        const int *__restrict__ qcount, int *__restrict__ nn, int stride,
                                                         int *__restrict__ nn_cnt) {
   extern __shared__ float lg_lds[];
-  const int q = blockIdx.x, lane = threadIdx.x;
-  if (!lit[q]) return;
+  const int lane = threadIdx.x;
+  // level 2: every query whose searched set hangs on a tie (grid = B); level 1: the listed queries (redone literally)
+  // whose group ORDER does (grid = a few workgroups walking qlist)
+  const int nq = qlist ? *qcount : (int)gridDim.x;
+  for (int fy = blockIdx.x; fy < nq; fy += gridDim.x) {
+  const int q = qlist ? qlist[fy] : fy;
+  if (lit[q] != level) continue;
   volatile float *hv = lg_lds;                                  // [cap]
   volatile int *hk = reinterpret_cast<volatile int *>(lg_lds + cap);   // [cap]
   const float *dq = cdist + (size_t)q * g;
@@ -360,6 +373,7 @@ __global__ __launch_bounds__(64) void gq_literal_groups(const float *__restrict_
   cnt = min(cnt, stride);
   for (int e = lane; e < cnt; e += 64) nn[(size_t)q * stride + e] = hk[e];
   if (lane == 0) nn_cnt[q] = cnt;
+  }
 }
 
 // ---- one searched group of one query -------------------------------------------------------------
@@ -780,6 +794,204 @@ __global__ __launch_bounds__(64) void gq_group_scan_wide(const uint16_t *__restr
   }
 }
 
+// ---- approximate pre-selection + exact re-ranking -------------------------------------------------------
+// The reference scores a row of a searched group through the residual's own table: one m x 256 table per (query,
+// group) pair -- 512 K tables of 98 Kflop per 1024-query batch at 10 M rows / LimitGroups(500), more work than
+// the scan they serve (8.4 ms per batch in round 1, against 3 ms for the flat index scanning 20 times the rows).
+// But the distance it computes is  |q - (g + r^_i)|^2  with  r^_i = decode(codes_i),  and
+//     |q - x^_i|^2 = |q|^2 - 2 q.g - 2 sum_j q_j . c_j[code_ij] + |x^_i|^2 ,      x^_i = g + r^_i ,
+// needs ONE table per QUERY (P[j][c] = -2 q_j . c_j[c], 16 KiB, shared by all its groups), one dot product per
+// (query, group) and one precomputed number per row.  That value D~ is not the reference's arithmetic, so it only
+// SELECTS: every query keeps the 64 rows with the smallest D~ of its searched groups (gq_approx_scan), those are
+// re-scored with the reference's arithmetic (gq_rerank: MathUtils.subtract, Index.prepareQuery's and
+// PQIndex.distances' summation order, bit for bit) and ordered by (distance, row); the answer is certified when
+// the (K+1)-th exact distance lies below the 64th D~ minus an error margin that bounds |D~ - exact| -- then no
+// row outside the 64 can reach the K+1 best.  Uncertified queries, queries with equal distances among their K+1
+// best and queries that saw a NaN go to the literal kernels as before, so results stay the reference's.
+__global__ void gq_row_norms(const uint8_t *__restrict__ codes, int ng, int vec, int m, int k, int d,
+                             const float *__restrict__ pq_cents, const int *__restrict__ from, const int *__restrict__ sdim,
+                             const float *__restrict__ gcent, const int *__restrict__ bounds, int g, int n,
+                             float *__restrict__ xnorm, unsigned *__restrict__ xnmax_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = g;                       // group of row i: largest c with bounds[c] <= i (empty groups skipped)
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bounds[mid] <= i) lo = mid; else hi = mid; }
+  const float *gc = gcent + (size_t)lo * d;
+  float acc = 0.f;
+  for (int j = 0; j < m; j++) {
+    const int code = codes[(((size_t)(i >> 6) * ng + j / vec) * 64 + (i & 63)) * vec + j % vec];
+    const int fr = from[j], sj = sdim[j];
+    const float *c = pq_cents + (size_t)k * fr + (size_t)code * sj;
+    for (int t = 0; t < sj; t++) { const float v = gc[fr + t] + c[t]; acc += v * v; }
+  }
+  xnorm[i] = acc;
+  atomicMax(xnmax_bits, __float_as_uint(acc == acc && acc < INFINITY ? acc : INFINITY));
+}
+
+// P[q][j][c] = -2 * (q_j . c_j[c]); entries beyond k (and padding quantizers) are 0
+__global__ __launch_bounds__(256) void gq_ptables(const float *__restrict__ pq_cents, const int *__restrict__ from,
+                                                  const int *__restrict__ sdim, int d, int m, int m_pad, int k,
+                                                  const float *__restrict__ Q, float *__restrict__ P) {
+  const int c = threadIdx.x, j = blockIdx.x, q = blockIdx.y;
+  float acc = 0.f;
+  if (j < m && c < k) {
+    const int fr = from[j], sj = sdim[j];
+    const float *cc = pq_cents + (size_t)k * fr + (size_t)c * sj;
+    for (int t = 0; t < sj; t++) acc += Q[(size_t)q * d + fr + t] * cc[t];
+    acc *= -2.0f;
+  }
+  P[((size_t)q * m_pad + j) * 256 + c] = acc;
+}
+
+constexpr int GA_WAVES = 16;    // waves of one query's workgroup: each takes every 16th searched group
+constexpr int GA_C = 64;        // candidates kept per query
+template <int VEC>
+__global__ __launch_bounds__(64 * GA_WAVES) void gq_approx_scan(const uint8_t *__restrict__ codes, int ng, int m_pad, int d,
+                                                                const float *__restrict__ P, const float *__restrict__ xnorm,
+                                                                const float *__restrict__ gcent,
+                                                                const int *__restrict__ bounds, const float *__restrict__ Q,
+                                                                const int *__restrict__ nn, int nn_stride,
+                                                                const int *__restrict__ nn_cnt, float *__restrict__ lv,
+                                                                int *__restrict__ li, int *__restrict__ nanflag) {
+  using Word = typename CodeWord<VEC>::type;
+  extern __shared__ float ga_lds[];           // m_pad * 256 table entries, then d query coordinates
+  float *tab = ga_lds, *qv = ga_lds + m_pad * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+  for (int e = tid; e < m_pad * 256; e += 64 * GA_WAVES) tab[e] = P[(size_t)q * m_pad * 256 + e];
+  for (int e = tid; e < d; e += 64 * GA_WAVES) qv[e] = Q[(size_t)q * d + e];
+  __syncthreads();
+  float qq = 0.f;
+  for (int e = lane; e < d; e += 64) qq += qv[e] * qv[e];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o);
+  WaveList wl;
+  wl.init();
+  int cnt = 0, saw_nan = 0;
+  const int ngroups = nn_cnt[q];
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  for (int t = wave; t < ngroups; t += GA_WAVES) {
+    const int c = nn[(size_t)q * nn_stride + t];
+    const int row_from = bounds[c], row_until = bounds[c + 1];
+    float qg = 0.f;
+    for (int e = lane; e < d; e += 64) qg += qv[e] * gcent[(size_t)c * d + e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qg += __shfl_xor(qg, o);
+    const float base = qq - 2.0f * qg;
+    const int rb_first = row_from >> 6, rb_end = (row_until + 63) >> 6;
+    Word wnext{};
+    if (rb_first < rb_end) wnext = cw[((size_t)rb_first * ng) * 64 + lane];
+    for (int rb = rb_first; rb < rb_end; rb++) {
+      const Word w0 = wnext;
+      if (rb + 1 < rb_end) wnext = cw[((size_t)(rb + 1) * ng) * 64 + lane];
+      const int row = rb * 64 + lane;
+      const bool valid = row >= row_from && row < row_until;
+      float acc = base + (valid ? xnorm[row] : 0.f);
+      for (int gi = 0; gi < ng; gi++) {
+        const Word w = gi == 0 ? w0 : cw[((size_t)rb * ng + gi) * 64 + lane];
+        const float *tj = tab + gi * VEC * 256;
+#pragma unroll
+        for (int b = 0; b < VEC; b++) acc += tj[b * 256 + code_byte<VEC>(w, b)];
+      }
+      if (__ballot(valid && acc != acc) != 0ull) saw_nan = 1;
+      unsigned long long mk = __ballot(valid && (cnt < GA_C || wl.accepts(acc, row)));
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float x = readlane_f(acc, l);
+        const int r = rb * 64 + l;
+        if (cnt < GA_C || wl.accepts(x, r)) {
+          wl.insert(x, r, GA_C, lane);
+          if (cnt < GA_C) cnt++;
+        }
+      }
+    }
+  }
+  const size_t o = ((size_t)q * GA_WAVES + wave) * GA_C;
+  lv[o + lane] = wl.v;
+  li[o + lane] = wl.i;
+  if (lane == 0) nanflag[q * GA_WAVES + wave] = saw_nan;
+}
+
+// 64-lane bitonic sort of (value, id) pairs, ascending by (value, id); padding = (+inf, INT_MAX)
+__device__ inline void sort64_pairs(float &v, int &id, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const float ov = __shfl_xor(v, j);
+      const int oi = __shfl_xor(id, j);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      const bool other_less = ov < v || (ov == v && oi < id);
+      const bool take = (lower == up) ? other_less : !other_less && !(ov == v && oi == id);
+      if (take) { v = ov; id = oi; }
+    }
+}
+
+// exact re-scoring of one query's candidates (lane = candidate) + certificate; see the block comment above
+__global__ __launch_bounds__(64) void gq_rerank(const uint8_t *__restrict__ codes, int ng, int vec, int m, int k, int d,
+                                                const float *__restrict__ pq_cents, const int *__restrict__ from,
+                                                const int *__restrict__ sdim, const float *__restrict__ gcent,
+                                                const int *__restrict__ bounds, int g, const float *__restrict__ Q,
+                                                const float *__restrict__ cv, const int *__restrict__ ci,
+                                                const int *__restrict__ nanflag, float xnmax, int K,
+                                                int *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                int *__restrict__ out_count, int *__restrict__ qlist,
+                                                int *__restrict__ qcount) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const float approx = cv[(size_t)q * GA_C + lane];
+  const int row = ci[(size_t)q * GA_C + lane];
+  const bool have = row != INT_MAX;
+  const int ncand = __popcll(__ballot(have));
+  const float a_last = readlane_f(approx, GA_C - 1);          // the largest kept D~ (every other row's is >= it)
+  float qq = 0.f;
+  for (int e = lane; e < d; e += 64) { const float x = Q[(size_t)q * d + e]; qq += x * x; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o);
+  float D = INFINITY;
+  if (have) {
+    int lo = 0, hi = g;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bounds[mid] <= row) lo = mid; else hi = mid; }
+    const float *gc = gcent + (size_t)lo * d;
+    const float *qp = Q + (size_t)q * d;
+    D = 0.f;                                                  // PQIndex.distances: 0 + T[0] + T[1] + ... (unfused fp32)
+    for (int j = 0; j < m; j++) {
+      const int code = codes[(((size_t)(row >> 6) * ng + j / vec) * 64 + (row & 63)) * vec + j % vec];
+      const int fr = from[j], sj = sdim[j];
+      const float *c = pq_cents + (size_t)k * fr + (size_t)code * sj;
+      float tj = 0.f;                                         // Index.prepareQuery on the residual (MathUtils.subtract)
+      for (int t = 0; t < sj; t++) { const float dd = (qp[fr + t] - gc[fr + t]) - c[t]; tj += dd * dd; }
+      D += tj;
+    }
+  }
+  const bool nan_d = __ballot(have && D != D) != 0ull;
+  float sv = have && D == D ? D : INFINITY;
+  int si = have && D == D ? row : INT_MAX;
+  sort64_pairs(sv, si, lane);
+  const int nfin = __popcll(__ballot(si != INT_MAX));
+  const int live = min(K, nfin);
+  if (lane < K) {
+    out_idx[(size_t)q * K + lane] = lane < live ? si : -1;
+    out_dist[(size_t)q * K + lane] = lane < live ? sv : INFINITY;
+  }
+  const float nv = __shfl_down(sv, 1);
+  const int ni = __shfl_down(si, 1);
+  const bool tie = lane < K && si != INT_MAX && ni != INT_MAX && sv == nv;      // equal neighbours among the K+1 best
+  // |D~ - exact| <= margin: both are sums of ~d + m terms of magnitude <= (|q| + |x^|)^2
+  const float xm = __fsqrt_rn(qq) + __fsqrt_rn(xnmax);
+  const float margin = 4.0f * (float)(d + 2 * m + 16) * 5.9604645e-8f * xm * xm;
+  bool certified = true;
+  if (ncand == GA_C) {                                        // rows were left out: the K+1 best must clear their bound
+    const float ek = readlane_f(sv, min(K, GA_C - 1));        // (K+1)-th exact distance (K <= 63)
+    certified = nfin > K && ek < a_last - margin && margin == margin && a_last == a_last;
+  }
+  int nanany = lane < GA_WAVES ? nanflag[q * GA_WAVES + lane] : 0;
+  const bool redo = !certified || nan_d || __ballot(tie) != 0ull || __ballot(nanany != 0) != 0ull;
+  if (lane == 0) {
+    if (out_count) out_count[q] = live;
+    if (redo) qlist[atomicAdd(qcount, 1)] = q;
+  }
+}
+
 // ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
 __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
                                                const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
@@ -889,6 +1101,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   // reference's leading empty group adds nothing to the count and is searched on top)
   const int nn_stride = std::max(1, (int)std::min<long long>((long long)limit + (strategy == 1 ? gx->n_empty : 0), g));
   int stride = nn_stride;
+  int lit_cap = 0;          // > 0: group selection went through the (distance, id) sorts; capacity of the literal heap
   gx->cdist.ensure((size_t)B * g);
   gx->nn.ensure((size_t)B * nn_stride);
   gx->nn_cnt.ensure((size_t)B);
@@ -929,7 +1142,16 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_literal_groups),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
         hipLaunchKernelGGL(gq_literal_groups, dim3(B), dim3(64), hl, st, gx->cdist.p, g, hcap, gx->bounds.p, strategy == 1,
-                           limit, gx->lit_flag.p, gx->nn.p, nn_stride, gx->nn_cnt.p);
+                           limit, gx->lit_flag.p, 2, (const int *)nullptr, (const int *)nullptr, gx->nn.p, nn_stride,
+                           gx->nn_cnt.p);
+        lit_cap = hcap;
+        if (ix->wide || getenv("GULON_GROUPED_LITERAL") != nullptr) {
+          // every query's result comes from the literal heaps, merged in search order: the order-only ties as well
+          hipLaunchKernelGGL(gq_literal_groups, dim3(B), dim3(64), hl, st, gx->cdist.p, g, hcap, gx->bounds.p, strategy == 1,
+                             limit, gx->lit_flag.p, 1, (const int *)nullptr, (const int *)nullptr, gx->nn.p, nn_stride,
+                             gx->nn_cnt.p);
+          lit_cap = 0;
+        }
       }
     }
     if (strategy == 1 && nn_stride > 64) {
@@ -1005,6 +1227,49 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   }
   // fast path for every query, then the literal heaps for the tie-flagged ones (usually none)
   HIP_CHECK(hipMemsetAsync(gx->qcount.p, 0, sizeof(int), st));
+  static const bool approx_off = [] { const char *e = getenv("GULON_GROUPED_APPROX"); return e && atoi(e) == 0; }();
+  const size_t lds_ga = ((size_t)ix->m_pad * 256 + ix->d) * sizeof(float);
+  if (!approx_off && gx->xnorm.n > 0 && lds_ga <= 150 * 1024) {
+    // approximate pre-selection with one table per query, exact re-ranking of 64 candidates, certificate
+    gx->ptab.ensure((size_t)B * ix->m_pad * 256);
+    gx->apv.ensure((size_t)B * GA_WAVES * GA_C); gx->api.ensure((size_t)B * GA_WAVES * GA_C);
+    gx->amv.ensure((size_t)B * GA_C); gx->ami.ensure((size_t)B * GA_C);
+    gx->anan.ensure((size_t)B * GA_WAVES);
+    hipLaunchKernelGGL(gq_ptables, dim3(ix->m_pad, B), dim3(256), 0, st, ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m,
+                       ix->m_pad, ix->k, dQ, gx->ptab.p);
+    {
+      auto kern = ix->vec == 16 ? gq_approx_scan<16> : gq_approx_scan<4>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_ga));
+      hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GA_WAVES), lds_ga, st, ix->codes.p, ix->ng, ix->m_pad, ix->d, gx->ptab.p,
+                         gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p, gx->apv.p,
+                         gx->api.p, gx->anan.p);
+    }
+    launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
+                 nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
+    hipLaunchKernelGGL(gq_rerank, dim3(B), dim3(64), 0, st, ix->codes.p, ix->ng, ix->vec, ix->m, ix->k, ix->d, ix->cents.p,
+                       ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, g, dQ, gx->amv.p, gx->ami.p, gx->anan.p, gx->xnmax,
+                       K, d_oi, d_od, d_oc, gx->qlist.p, gx->qcount.p);
+    HIP_CHECK(hipGetLastError());
+    if (getenv("GULON_GROUPED_STATS")) {   // debugging aid
+      HIP_CHECK(hipStreamSynchronize(st));
+      int nfl = 0;
+      HIP_CHECK(hipMemcpy(&nfl, gx->qcount.p, sizeof(int), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[grouped] approximate pre-selection: %d of %d queries redone with literal heaps\n", nfl, B);
+    }
+    if (lit_cap > 0) {   // listed queries whose group ORDER hangs on equal centroid distances: the reference's heap order
+      hipLaunchKernelGGL(gq_literal_groups, dim3(std::min(B, 16)), dim3(64), (size_t)lit_cap * 8, st, gx->cdist.p, g, lit_cap,
+                         gx->bounds.p, strategy == 1, limit, gx->lit_flag.p, 1, gx->qlist.p, gx->qcount.p, gx->nn.p, nn_stride,
+                         gx->nn_cnt.p);
+      HIP_CHECK(hipGetLastError());
+    }
+    const int fy = std::min(B, 16);
+    scan(true, fy, gx->qlist.p, gx->qcount.p);
+    hipLaunchKernelGGL(gq_merge, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+                       d_od, d_oc, gx->qlist.p, gx->qcount.p);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const size_t lds_qm = (4 * (size_t)smax * 256 + (size_t)QM_WAVES * (512 + ix->d)) * sizeof(float);
   const char *qm_env = getenv("GULON_GROUPED_QM");   // testing aid: 0 = never, 1 = whenever it applies
   const bool qm_off = qm_env && atoi(qm_env) == 0, qm_force = qm_env && atoi(qm_env) == 1;
@@ -1058,6 +1323,14 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     HIP_CHECK(hipMemcpy(&nfl, gx->qcount.p, sizeof(int), hipMemcpyDeviceToHost));
     fprintf(stderr, "[grouped] %d of %d queries redone with literal heaps; %d groups searched per query at most\n", nfl, B,
             stride);
+  }
+  {
+    if (lit_cap > 0) {   // listed queries whose group ORDER hangs on equal centroid distances: the reference's heap order
+      hipLaunchKernelGGL(gq_literal_groups, dim3(std::min(B, 16)), dim3(64), (size_t)lit_cap * 8, st, gx->cdist.p, g, lit_cap,
+                         gx->bounds.p, strategy == 1, limit, gx->lit_flag.p, 1, gx->qlist.p, gx->qcount.p, gx->nn.p, nn_stride,
+                         gx->nn_cnt.p);
+      HIP_CHECK(hipGetLastError());
+    }
   }
   const int fy = std::min(B, 16);
   scan(true, fy, gx->qlist.p, gx->qcount.p);
@@ -1132,6 +1405,17 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
     }
     gx->bounds.upload(bounds.data(), bounds.size());
     HIP_CHECK(hipDeviceSynchronize());
+    if (!pq->wide && n > 0) {   // |g + decode(codes_i)|^2 per row: the per-row term of the approximate pre-selection
+      gx->xnorm.alloc((size_t)n);
+      DevBuf<unsigned> mx(1);
+      HIP_CHECK(hipMemset(mx.p, 0, sizeof(unsigned)));
+      hipLaunchKernelGGL(gq_row_norms, dim3(ceil_div(n, 256)), dim3(256), 0, 0, pq->codes.p, pq->ng, pq->vec, pq->m, pq->k, d,
+                         pq->cents.p, pq->from.p, pq->sdim.p, gx->gcent.p, gx->bounds.p, g, n, gx->xnorm.p, mx.p);
+      HIP_CHECK(hipGetLastError());
+      unsigned h = 0;
+      HIP_CHECK(hipMemcpy(&h, mx.p, sizeof(h), hipMemcpyDeviceToHost));
+      memcpy(&gx->xnmax, &h, sizeof(float));
+    }
     *out = gx.release();
   });
 }
