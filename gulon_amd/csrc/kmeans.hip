@@ -630,9 +630,6 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
   float p = 0.f;
   if (len == 0) { D.cout[c * s + j] = 0.f; return; }
   const float *col = D.xb + (size_t)D.start[c] * sp + j;
-#ifdef GULON_CHAINS_EXPT
-  col = D.xb + (size_t)D.start[c] * sp;   // timing experiment: 10 lanes share an address
-#endif
   constexpr int U = 32;
   const unsigned last = len - 1;
   unsigned i = 0;
@@ -645,8 +642,13 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
     const float *nxt = col + (size_t)2 * U * sp;
     // batches whose look-ahead (two batches) stays inside the cluster
     for (; i + 3 * U <= len; i += U, nxt += (size_t)U * sp) {
+#ifdef GULON_CHAINS_NOLOAD   // timing experiment (wrong results): the recurrence alone, no loads in the loop --
+#pragma unroll              // 5.5 ms against 8.4 ms for the first update at BASELINE config 3 (longest chain: 118 K steps)
+      for (int u = 0; u < U; u++) xc[u] = xa[u] * 1.0001f;
+#else
 #pragma unroll
       for (int u = 0; u < U; u++) xc[u] = nxt[(size_t)u * sp];
+#endif
       const float p0 = p;
       float lo = INFINITY, hi = 0.f;
       float nf = (float)(int)(i + 1);
@@ -1099,8 +1101,9 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     AssignJob job;
     bool use_mfma = false;
     bool done = false;
+    bool shared_stream = false;
     int nrep = 0;
-    ~Prob() { if (st) (void)hipStreamDestroy(st); }
+    ~Prob() { if (st && !shared_stream) (void)hipStreamDestroy(st); }
   };
   std::vector<Prob> P(np);
   auto push_report = [&](int p, const gulon_kmeans_report &r) {
@@ -1139,7 +1142,11 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     all[p] = p;
     const int s = sdim[p];
     Prob &pr = P[p];
-    HIP_CHECK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
+    // GULON_KMEANS_SERIAL=1 (profiling): every problem on the batch stream, so that kernels run one at a time and
+    // rocprofv3's per-kernel durations are not inflated by the other sub-quantizers' concurrent launches
+    static const bool serial = getenv("GULON_KMEANS_SERIAL") != nullptr;
+    if (serial) { pr.st = bst; pr.shared_stream = true; }
+    else HIP_CHECK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
     pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
     pr.a_prev.alloc(n); pr.a_next.alloc(n);
     pr.mism.alloc(1);
