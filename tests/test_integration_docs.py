@@ -23,7 +23,7 @@ def test_jni_names_agree_everywhere():
             md.update(re.findall(r"`(\w+)`", cells[2]))
     assert c_names == scala, (sorted(c_names - scala), sorted(scala - c_names))
     assert c_names == md, (sorted(c_names - md), sorted(md - c_names))
-    assert len(c_names) >= 24
+    assert len(c_names) >= 23
 
 
 def test_glue_calls_only_declared_entry_points_and_includes_stdlib():
