@@ -622,7 +622,7 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 }  // namespace
 
 bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
-  const ScanTuning &t = tuning();
+  const ScanTuning &t = tuning_of(ix);
   return t.filter && !ix->wide && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 256 * 4 <= FILTER_LDS_BUDGET &&
          rb_total >= t.filter_min_rb && rb_total >= t.filter_period;
 }
@@ -630,7 +630,7 @@ bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
 void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
                       float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st,
                       const SharedBounds *sb) {
-  const ScanTuning &t = tuning();
+  const ScanTuning &t = tuning_of(ix);
   const int phase = sb ? sb->phase : 0;
   const int keff = K + 1;
   const int W = ix->w;               // fp32 table interleave of the exact kernels

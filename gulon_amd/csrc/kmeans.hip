@@ -547,7 +547,11 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
   for (int u = tid; u < units; u += 256) {
     const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
     const int part = u - lp * h;
+#ifdef GULON_PLACE_EXPT   // timing experiment (wrong results): the chunk's sorted slices written back contiguously
+    dst2[(size_t)r0 * h + u] = src2[u];
+#else
     dst2[(size_t)dstrow[lp] * h + part] = src2[u];
+#endif
   }
 }
 

@@ -676,7 +676,7 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
   if (merge_bytes > lds_bytes) lds_bytes = merge_bytes;
   const int tau_off4 = (int)(lds_bytes / sizeof(float4));   // shared thresholds live after tables/merge area
   lds_bytes += 64;
-  int prune_from = tuning().prune_from >= 0 ? tuning().prune_from : ix->m_pad / 2;
+  int prune_from = tuning_of(ix).prune_from >= 0 ? tuning_of(ix).prune_from : ix->m_pad / 2;
   if (prune_from < 4) prune_from = 4;
   unsigned long long *dbg = nullptr;
   if (getenv("GULON_SCAN_TIMELINE") && !tile_enable) {
@@ -733,7 +733,7 @@ void launch_scan_t(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
                    int from, int until, int keff, hipStream_t st, const float *lbv, const int *lbi,
                    const int *tile_enable, int tile_div, int grid_x, int *hint) {
   constexpr int TH = 1024;
-  if (tuning().prune)
+  if (tuning_of(ix).prune)
     launch_scan_p<W, NSUB, VEC, TH, true>(ix, ntiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, keff,
                                           st, lbv, lbi, tile_enable, tile_div, grid_x, hint);
   else
@@ -830,8 +830,8 @@ void run_query(gulon_index *ix, const float *dQ, int B, int K, int from, int unt
     return;
   }
   // chunking: ~4096 workgroups, at least 2 row blocks per wave
-  const int NW = tuning().threads / 64;
-  int want = ceil_div(tuning().target_blocks, ntiles);
+  const int NW = tuning_of(ix).threads / 64;
+  int want = ceil_div(tuning_of(ix).target_blocks, ntiles);
   int max_chunks = rb_total / (2 * NW);
   if (max_chunks < 1) max_chunks = 1;
   int nchunks = want < max_chunks ? want : max_chunks;
@@ -1014,6 +1014,7 @@ gulon_index *make_context(gulon_index *parent) {
   c->vec = parent->vec; c->ng = parent->ng; c->m_pad = parent->m_pad; c->nsub = parent->nsub; c->w = parent->w;
   c->wide = parent->wide;
   c->cents_absmax = parent->cents_absmax;
+  c->tune = parent->tune;
   c->codes.borrow(parent->codes);
   c->wcodes.borrow(parent->wcodes);
   c->cents.borrow(parent->cents);
@@ -1227,6 +1228,17 @@ GULON_API int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tile
     }
     if (query_tiles) *query_tiles = nt;
     if (tiles_redone) *tiles_redone = redone;
+  });
+}
+
+GULON_API int32_t gulon_index_tuning(gulon_index *idx, const char *key, int32_t value) {
+  return guarded([&] {
+    GULON_REQUIRE(idx != nullptr && key != nullptr, "null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    // copy-on-write: contexts created earlier keep the settings they were created with
+    auto t = std::make_shared<ScanTuning>(tuning_of(idx));
+    GULON_REQUIRE(t->set(key, value), "unknown tuning key");
+    idx->tune = t;
   });
 }
 

@@ -23,9 +23,13 @@ void launch_peel_finalize(const float *pv, const int *pi, int B, int cap, int K,
                           int *out_count, int *out_flags, hipStream_t st);
 }  // namespace gulon
 
+namespace gulon { struct ScanTuning; }
 // PQIndex on the device (opaque to C callers)
 using gulon::DevBuf;
 struct gulon_index {
+  // launch-shape / algorithm knobs of THIS handle (gulon_index_tuning); null: the process-wide defaults
+  // (gulon_scan_tuning).  Contexts inherit their parent's at creation.
+  std::shared_ptr<gulon::ScanTuning> tune;
   int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
   int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
   DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
@@ -154,6 +158,7 @@ struct ScanTuning {
   bool set(const char *key, int v);
 };
 ScanTuning &tuning();
+inline const ScanTuning &tuning_of(const gulon_index *ix) { return ix && ix->tune ? *ix->tune : tuning(); }
 
 // wide.hip: indexes with more than 256 centroids per quantizer (code widths 10/12/16)
 void wide_store_codes(gulon_index *ix, const uint16_t *wide16 /* device, [m][n] */);

@@ -348,6 +348,9 @@ int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tiles, int32_t
  * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
  * "GULON_FILTER_NADD", "GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE".  Results never depend on them. */
 int32_t gulon_scan_tuning(const char *key, int32_t value);
+/* The same knobs for ONE handle (and the contexts created from it afterwards): two indexes of a process can be
+ * tuned independently; a handle without settings of its own follows the process-wide ones. */
+int32_t gulon_index_tuning(gulon_index *idx, const char *key, int32_t value);
 /* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
  * the deterministic (distance, row id) order: merges `lists` partial lists per
  * query, laid out [lists][B][K+1], into the final K.  list_stride = elements

@@ -218,3 +218,25 @@ def test_c_abi_sharded_index_large_k(oracle, g, devices, K):
         if res[3][q] == 0:
             assert np.array_equal(res[0][q], oi[q])
     sx.close()
+
+
+def test_two_indexes_tuned_independently(oracle, g):
+    """gulon_index_tuning: the knobs of one handle do not leak into another index of the same process."""
+    import ctypes as C
+    from gulon_amd import native as N
+    n, d, m, k, K, B = 90000, 32, 8, 256, 10, 9
+    cents, idx, pq, enc = _make(g, n, d, m, k, seed=77)
+    Q = np.random.default_rng(5).standard_normal((B, d)).astype(np.float32)
+    a, b = g.PQIndex(pq, enc), g.PQIndex(pq, enc)
+    N.check(N.lib().gulon_index_tuning(a._h, b"GULON_SCAN_FILTER", 0))      # a: exact scan only
+    exp = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    _check(a.batch_query_raw(K, Q), *exp)
+    _check(b.batch_query_raw(K, Q), *exp)
+    t, r = C.c_int32(-1), C.c_int32(-1)
+    N.check(N.lib().gulon_index_filter_stats(a._h, C.byref(t), C.byref(r)))
+    assert t.value == 0                                                    # a's batch took the exact scan ...
+    N.check(N.lib().gulon_index_filter_stats(b._h, C.byref(t), C.byref(r)))
+    assert t.value > 0                                                     # ... b's the filter
+    with pytest.raises(ValueError):
+        N.check(N.lib().gulon_index_tuning(a._h, b"NO_SUCH_KNOB", 1))
+    a.close(); b.close()
