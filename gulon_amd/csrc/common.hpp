@@ -103,6 +103,16 @@ struct DevBuf {
   }
 };
 
+// A pointer the device reads out of memory (a descriptor struct, an opaque register copy) is "generic" to the compiler
+// and dereferenced with FLAT instructions.  A flat access counts in lgkmcnt as well as vmcnt (it might have hit LDS),
+// so every wait for an LDS or scalar result also waits for the global traffic in flight -- phases that should overlap
+// run one after the other.  as_global() states the address space: global_load / global_store, vmcnt only.
+template <class T> using gptr = T __attribute__((address_space(1))) *;
+template <class T> __device__ __forceinline__ gptr<T> as_global(T *p) { return (gptr<T>)p; }
+// (HIP's float2 / float4 are classes whose operators expect generic `this`: global pointers use the native vectors)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Vectors.subvectors (Vectors.scala:84-104)

@@ -323,7 +323,7 @@ constexpr int CHUNK_ROWS = 1024;   // rows per workgroup-chunk of the counting s
 
 // per chunk histogram: hist[chunk][k]
 __global__ __launch_bounds__(256) void sort_hist(const UpdDesc *__restrict__ descs, int n, int k) {
-  const UpdDesc D = descs[blockIdx.y];
+  const UpdDescG D = load_desc(descs, blockIdx.y);
   extern __shared__ unsigned sh[];  // k
   for (int c = threadIdx.x; c < k; c += 256) sh[c] = 0;
   __syncthreads();
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void sort_hist(const UpdDesc *__restrict__ des
 // level 1: one thread per (group of SCAN_GROUP chunks, cluster) scans its chunks in place
 constexpr int SCAN_GROUP = 64;
 __global__ void sort_scan_groups(const UpdDesc *__restrict__ descs, long long nchunks, int k) {
-  const UpdDesc D = descs[blockIdx.z];
+  const UpdDescG D = load_desc(descs, blockIdx.z);
   int c = blockIdx.y * blockDim.x + threadIdx.x;
   long long g = blockIdx.x;
   if (c >= k) return;
@@ -354,7 +354,7 @@ __global__ void sort_scan_groups(const UpdDesc *__restrict__ descs, long long nc
 }
 // level 2: one thread per cluster scans the group totals; then cluster starts
 __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngroups, int k) {
-  const UpdDesc D = descs[blockIdx.y];
+  const UpdDescG D = load_desc(descs, blockIdx.y);
   extern __shared__ unsigned cnt[];  // k
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
     unsigned run = 0;
@@ -402,10 +402,23 @@ __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngrou
 //      21 ms against ~5 ms at BASELINE config 3: partial-line stores do not combine).
 // STAGED needs k <= 1024 and sp <= 16 (LDS); otherwise the slices go straight to their positions.
 template <int SMAX /* 0: slices go straight to their positions; else staged, s <= SMAX */>
-__global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits) {
+__global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits,
+                                                  int cpx /* > 0: chunks per XCD, 1-D grid */) {
   constexpr bool STAGED = SMAX > 0;
   constexpr int NV = STAGED ? SMAX : 1;
-  const UpdDesc D = descs[blockIdx.y];
+  // Which chunk: workgroups are dealt round-robin over the 8 XCDs (observed, for speed only), and a chunk's run of a
+  // cluster continues where the previous chunk's ended -- two partial lines per 160-byte run at BASELINE config 3.
+  // With consecutive chunks on the SAME XCD, at about the same time, the halves of a line meet in that XCD's L2 and
+  // leave as one full line; dealt over eight L2s every run is written back as partial lines.
+  int prob = blockIdx.y;
+  long long chunk = blockIdx.x;
+  if (cpx > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    prob = slot / cpx;
+    chunk = (long long)xcd * cpx + (slot - prob * cpx);
+    if (chunk * CHUNK_ROWS >= n) return;
+  }
+  const UpdDescG D = load_desc(descs, prob);
   extern __shared__ unsigned sh[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned *wh = sh;                                  // [4][k] per-wave counts, then running positions
@@ -414,27 +427,26 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
   unsigned short *lpos = reinterpret_cast<unsigned short *>(sh + 5 * k + CHUNK_ROWS);   // STAGED: [CHUNK_ROWS] local position of a chunk row
   float *sorted = reinterpret_cast<float *>(sh + ((5 * k + CHUNK_ROWS + CHUNK_ROWS / 2 + 1) & ~1));   // STAGED: [CHUNK_ROWS][sp], 8-byte aligned
   __shared__ unsigned wave_tot[4];
-  const long long chunk = blockIdx.x;
   const long long r0 = chunk * CHUNK_ROWS;
   const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
   const long long grp = chunk / SCAN_GROUP;
   const int s = D.s, sp = (s + 1) & ~1;
   // STAGED: the wave's 256 slices are 256 * s consecutive floats of the compact source = 64 * s float4: all of them
   // requested now (s loads of 16 bytes per lane), consumed after the positions are known
-  float4 v[NV];
+  f32x4 v[NV];
   const long long wr0 = r0 + wave * 256;                          // first row of this wave
   const int wrows = (int)max(0ll, min(256ll, r1 - wr0));          // its rows
   if (STAGED) {
-    const float4 *src4 = reinterpret_cast<const float4 *>(D.x + (size_t)wr0 * s);
+    const auto src4 = reinterpret_cast<gptr<const f32x4>>(D.x + (size_t)wr0 * s);
     const int nf4 = wrows * s / 4, tail0 = nf4 * 4, total = wrows * s;   // whole float4s, then up to 3 floats
 #pragma unroll
     for (int u = 0; u < NV; u++) {
       const int f = lane + 64 * u;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (u < s) {
         if (f < nf4) v[u] = src4[f];
         else if (f == nf4 && tail0 < total) {
-          const float *tp = D.x + (size_t)wr0 * s + tail0;
+          const auto tp = D.x + (size_t)wr0 * s + tail0;
           v[u].x = tp[0];
           if (tail0 + 1 < total) v[u].y = tp[1];
           if (tail0 + 2 < total) v[u].z = tp[2];
@@ -509,10 +521,10 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
     if (STAGED) {
       if (valid) { dstrow[pos] = (int)(gpos[key] + pos); lpos[wave * 256 + t * 64 + lane] = (unsigned short)pos; }
     } else if (valid) {
-      float *dst = D.xb + (size_t)pos * sp;
-      const float *src = D.x + (size_t)r * D.ld + D.from;
+      const auto dst = D.xb + (size_t)pos * sp;
+      const auto src = D.x + (size_t)r * D.ld + D.from;
       int j = 0;
-      for (; j + 2 <= s; j += 2) *reinterpret_cast<float2 *>(dst + j) = make_float2(src[j], src[j + 1]);
+      for (; j + 2 <= s; j += 2) *reinterpret_cast<gptr<f32x2>>(dst + j) = f32x2{src[j], src[j + 1]};
       if (j < s) dst[j] = src[j];
     }
   }
@@ -542,8 +554,8 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
   const int h = sp >> 1;
   const int units = (int)(r1 - r0) * h;
   const unsigned hdiv = ((1u << 20) + (unsigned)h - 1u) / (unsigned)h;   // u / h == (u * hdiv) >> 20 for u < 8192, h <= 8
-  const float2 *src2 = reinterpret_cast<const float2 *>(sorted);
-  float2 *dst2 = reinterpret_cast<float2 *>(D.xb);
+  const f32x2 *src2 = reinterpret_cast<const f32x2 *>(sorted);
+  const auto dst2 = reinterpret_cast<gptr<f32x2>>(D.xb);
   for (int u = tid; u < units; u += 256) {
     const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
     const int part = u - lp * h;
@@ -552,6 +564,192 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
 #else
     dst2[(size_t)dstrow[lp] * h + part] = src2[u];
 #endif
+  }
+}
+
+// The staged placement as a STREAM: the launch holds as many workgroups as the chip keeps resident, each walks its
+// share of the (problem, chunk) items, and the loads of the NEXT item -- slices, keys, bucket bases -- are requested
+// before the current item is sorted and written, so that a workgroup's memory latency passes under its own work
+// (one item per workgroup: load, barrier, sort, barrier, store, each phase waiting for the one before; 8.7 ms at
+// BASELINE config 3, 7.2 with the XCD mapping, both far from the 4 ms the 24.8 GB cost at streaming rate).
+// Items are dealt so that the workgroups of an XCD work on consecutive chunks of one problem at about the same time
+// (see sort_place): item j of XCD x = problem j / cpx, chunk x * cpx + j % cpx; workgroup w of the XCD takes
+// j = w, w + G, w + 2G, ...
+template <int SMAX, int PER_MAX /* clusters per thread in the chunk-local scan: 1 (k <= 256) or 4 (k <= 1024) */>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMAX > 10 ? 2 : 3, SMAX > 10 ? 2 : 3))) void sort_place_stream(
+    const UpdDesc *__restrict__ descs, int np, int n, int k, int key_bits, int cpx, int G, int dbg) {
+  constexpr int NV = SMAX;
+  extern __shared__ unsigned sh[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned *wh = sh;                                  // [4][k] per-wave counts, then running positions
+  unsigned *gpos = sh + 4 * k;                        // [k] bucket position of chunk-local position 0
+  int *dstrow = reinterpret_cast<int *>(sh + 5 * k);  // [CHUNK_ROWS] bucket position of a local position
+  unsigned short *rowof = reinterpret_cast<unsigned short *>(sh + 5 * k + CHUNK_ROWS);   // [CHUNK_ROWS] chunk row at a local position
+  float *raw = reinterpret_cast<float *>(sh + ((5 * k + CHUNK_ROWS + CHUNK_ROWS / 2 + 3) & ~3));   // [CHUNK_ROWS][s] as loaded (+1), 16-byte aligned
+  __shared__ unsigned wave_tot[4];
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+  const int nchunks = (n + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  const int cx = min(cpx, nchunks - xcd * cpx);   // this XCD's chunks: [xcd * cpx, xcd * cpx + cx)
+  if (cx <= 0) return;
+  const int items = np * cx;
+  const int per = (k + 255) / 256;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  struct Item {
+    f32x4 v[NV];
+    int keys[4];
+    unsigned g[PER_MAX][3];   // bucket base of the thread's clusters, as its three terms (added when consumed: no wait here)
+  };
+  // the item's problem: descriptors change once per cpx items, so they are re-read only then
+  int d_prob = -1;
+  UpdDescG D{};
+  auto desc = [&](int prob) { if (prob != d_prob) { D = load_desc(descs, prob); d_prob = prob; } };
+  // requests everything item j needs from memory; nothing is waited for here
+  auto fetch = [&](int j, Item &it) {
+    const int prob = j / cx;
+    const long long chunk = (long long)xcd * cpx + (j - prob * cx);
+    const long long r0 = chunk * CHUNK_ROWS;
+    desc(prob);
+    const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
+    const int s = D.s;
+    const long long wr0 = r0 + wave * 256;
+    const int wrows = (int)max(0ll, min(256ll, r1 - wr0));
+    // whole float4s only, every lane a valid address (clamped: no divergent branches around the loads); the up to
+    // three floats behind them -- the last wave of the last chunk when its rows * s is no multiple of 4 -- are read by
+    // the consumer
+    const auto src4 = reinterpret_cast<gptr<const f32x4>>(D.x + (size_t)wr0 * s);
+    const int nf4 = wrows * s / 4;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int f = min(lane + 64 * u, max(nf4 - 1, 0));
+      it.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < s && nf4 > 0 && !(dbg & 8)) it.v[u] = (dbg & 16) ? src4[f] : __builtin_nontemporal_load(&src4[f]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const long long r = wr0 + t * 64 + lane;
+      it.keys[t] = r < r1 ? D.assign[r] : 0;
+    }
+    const long long grp = chunk / SCAN_GROUP;
+#pragma unroll
+    for (int q = 0; q < PER_MAX; q++) {
+      const int c = tid * per + q;
+      const int cc = q < per && c < k ? c : 0;
+      it.g[q][0] = D.start[cc];
+      it.g[q][1] = D.gtot[(size_t)grp * k + cc];
+      it.g[q][2] = D.hist[(size_t)chunk * k + cc];
+    }
+  };
+
+  // vmcnt counts loads and stores together, in order: a wait for the next item's slices that comes AFTER this item's
+  // stores in program order also waits for those stores (8.5 ms; 2.7 ms with the stores taken out).  So the look-ahead
+  // is taken over into `cur` just BEFORE the stores are issued -- requested a whole sort earlier, it has long arrived --
+  // and the stores drain under the next item's sort.
+  Item cur, nxt;
+  if (w < items) { fetch(w, nxt); cur = nxt; }
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the loop is entered with nothing pending, as on its back edge
+  for (int j = w; j < items; j += G) {
+    const int prob = j / cx;
+    const long long chunk = (long long)xcd * cpx + (j - prob * cx);
+    const long long r0 = chunk * CHUNK_ROWS;
+    // this item's descriptor fields before the look-ahead moves on to (possibly) the next problem
+    desc(prob);
+    const int s = D.s;
+    const auto xb = D.xb;
+    if (j + G < items) fetch(j + G, nxt);
+    const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
+    const int sp = (s + 1) & ~1;
+    const long long wr0 = r0 + wave * 256;
+    __syncthreads();                             // the previous item's stage D has read `raw`, `rowof`, `dstrow`
+    for (int e = tid; e < 4 * k; e += 256) wh[e] = 0;
+    // the wave's slices into LDS as they came (row-major, compact): 16 bytes per lane and load, no conflicts
+    if (!(dbg & 2)) {
+      f32x4 *raw4 = reinterpret_cast<f32x4 *>(raw + (size_t)wave * 256 * s);   // 256 * s floats = 64 * s float4
+      const int wrows = (int)max(0ll, min(256ll, r1 - wr0));
+      const int nf4 = wrows * s / 4;
+#pragma unroll
+      for (int u = 0; u < NV; u++)
+        if (u < s && lane + 64 * u < nf4) raw4[lane + 64 * u] = cur.v[u];
+      if (nf4 * 4 < wrows * s) {                  // (rare, uniform) the floats behind the last whole float4
+        const int e = nf4 * 4 + lane;
+        if (e < wrows * s) raw[(size_t)wave * 256 * s + e] = D.x[(size_t)wr0 * s + e];
+      }
+    }
+    __syncthreads();
+    // A: per-wave counts (the lanes holding the same cluster: one ballot per key bit)
+    unsigned long long same[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const bool valid = wr0 + t * 64 + lane < r1;
+      unsigned long long sm = __ballot(valid);
+      for (int bit = 0; bit < key_bits; bit++) {
+        const unsigned long long bm = __ballot((cur.keys[t] >> bit) & 1);
+        sm &= ((cur.keys[t] >> bit) & 1) ? bm : ~bm;
+      }
+      same[t] = valid ? sm : 0ull;
+      if (valid && (sm & lt) == 0ull) wh[wave * k + cur.keys[t]] += (unsigned)__popcll(sm);
+    }
+    __syncthreads();
+    // B: exclusive scan of the chunk's cluster totals; first position of every (cluster, wave)
+    {
+      unsigned mine = 0;
+      for (int c = tid * per; c < min(k, tid * per + per); c++) mine += wh[c] + wh[k + c] + wh[2 * k + c] + wh[3 * k + c];
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      unsigned base = incl - mine;
+      for (int ww = 0; ww < wave; ww++) base += wave_tot[ww];
+#pragma unroll
+      for (int q = 0; q < PER_MAX; q++) {
+        const int c = tid * per + q;
+        if (q < per && c < k) {
+          const unsigned t0 = wh[c], t1 = wh[k + c], t2 = wh[2 * k + c], t3 = wh[3 * k + c];
+          gpos[c] = cur.g[q][0] + cur.g[q][1] + cur.g[q][2] - base;
+          wh[c] = base; wh[k + c] = base + t0; wh[2 * k + c] = base + t0 + t1; wh[3 * k + c] = base + t0 + t1 + t2;
+          base += t0 + t1 + t2 + t3;
+        }
+      }
+    }
+    __syncthreads();
+    // C: placement (same-wave LDS accesses execute in program order): local position -> bucket position and chunk row
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const bool valid = wr0 + t * 64 + lane < r1;
+      const int key = cur.keys[t];
+      const unsigned b = valid ? wh[wave * k + key] : 0u;
+      const unsigned pos = b + (unsigned)__popcll(same[t] & lt);
+      if (valid && (same[t] & lt) == 0ull) wh[wave * k + key] = b + (unsigned)__popcll(same[t]);
+      if (valid) { dstrow[pos] = (int)(gpos[key] + pos); rowof[pos] = (unsigned short)(wave * 256 + t * 64 + lane); }
+    }
+    __syncthreads();
+    // D: the slices leave in sorted order as float2 units -- consecutive units of a cluster's run are consecutive in
+    // memory; a unit is gathered from its row's place in `raw` (two dwords: rows of an odd s start on odd words; the
+    // padding half of an odd s's last unit reads the neighbouring word, which nobody looks at).  The trip count is a
+    // compile-time constant: the stores of this item must not hide the count of outstanding memory operations from
+    // the wait for the NEXT item's loads at the top of the loop (vmcnt counts both, in order).
+    const int h = sp >> 1;
+    const int units = (int)(r1 - r0) * h;
+    const unsigned hdiv = ((1u << 20) + (unsigned)h - 1u) / (unsigned)h;   // u / h == (u * hdiv) >> 20 for u < 8192, h <= 8
+    const auto dst2 = reinterpret_cast<gptr<f32x2>>(xb);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), HERE: every load in flight is the look-ahead's
+    cur = nxt;                                   // (nothing below reads `cur`)
+    if (!(dbg & 1)) {
+#pragma unroll
+      for (int it = 0; it < CHUNK_ROWS * ((SMAX + 1) / 2) / 256; it++) {
+        const int u = tid + 256 * it;
+        if (u < units) {
+          const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
+          const int part = u - lp * h;
+          const float *src = raw + (size_t)rowof[lp] * s + 2 * part;
+          dst2[(size_t)dstrow[lp] * h + part] = f32x2{src[0], src[1]};
+        }
+      }
+    }
   }
 }
 
@@ -622,18 +820,18 @@ __global__ void mean_division_selftest(int n_max, int per, unsigned long long se
 // main loop runs clear of the cluster's end (no index clamps), and the range test of the fast quotient is one
 // min and one max per step, looked at once per batch.
 template <int SP /* bucket row stride in floats; 0: read it from the descriptor */>
-__global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ descs, int k) {
-  const UpdDesc D = descs[blockIdx.x];            // x = problem, y = block of 64 chains: blocks are dispatched x-fastest,
+__global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ descs, int k,
+                                                    const float *__restrict__ rcp /* scalar loads: see update_chains_pk */) {
+  const UpdDescG D = load_desc(descs, blockIdx.x);           // x = problem, y = block of 64 chains: blocks are dispatched x-fastest,
   const int s = D.s, sp = SP ? SP : ((s + 1) & ~1);   // so every problem's longest chains (block 0) come first
   int t = blockIdx.y * blockDim.x + threadIdx.x;
   if (t >= k * s) return;
   const int slot = t / s, j = t - slot * s;
   const int c = D.corder ? D.corder[slot] : slot;
   const unsigned len = D.count[c];
-  const float *__restrict__ rcp = D.rcp;
   float p = 0.f;
   if (len == 0) { D.cout[c * s + j] = 0.f; return; }
-  const float *col = D.xb + (size_t)D.start[c] * sp + j;
+  const auto col = D.xb + (size_t)D.start[c] * sp + j;
   constexpr int U = 32;
   const unsigned last = len - 1;
   unsigned i = 0;
@@ -643,7 +841,7 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
     for (int u = 0; u < U; u++) xa[u] = col[(size_t)u * sp];
 #pragma unroll
     for (int u = 0; u < U; u++) xb[u] = col[(size_t)(U + u) * sp];
-    const float *nxt = col + (size_t)2 * U * sp;
+    auto nxt = col + (size_t)2 * U * sp;
     // batches whose look-ahead (two batches) stays inside the cluster
     for (; i + 3 * U <= len; i += U, nxt += (size_t)U * sp) {
 #ifdef GULON_CHAINS_NOLOAD   // timing experiment (wrong results): the recurrence alone, no loads in the loop --
@@ -683,6 +881,105 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
   }
   for (; i <= last; i++) p = p + __fdiv_rn(col[(size_t)i * sp] - p, (float)(int)(i + 1));
   D.cout[c * s + j] = p;
+}
+
+// Two chains per lane on the packed fp32 pipe.  The chain kernel is latency bound -- five dependent operations per
+// step, nothing to overlap them with -- and with one (cluster, dim) per lane BASELINE config 3 needs 1280 waves for
+// 1024 SIMDs: the SIMDs holding two pay every step twice.  v_pk_add/mul/fma_f32 carry two IEEE binary32 lanes per
+// register pair at the cost of one instruction, so lane = (cluster, PAIR of dims): 640 waves, one per SIMD, and the
+// per-step instruction stream (5 packed + min3 + max3 + one 8-byte load) is no longer than the scalar one was.
+// The bucket row stride is even (sort_place), so the pair is one aligned 8-byte load; the second half of the last
+// pair of an odd s walks the padding column (whatever sort_place left there): it mirrors the first half instead
+// and is never stored.
+// `rcp` arrives as a kernel argument of its own (every problem shares the device's table): a restrict-qualified
+// argument indexed by the wave-uniform step number becomes scalar loads.  As vector loads the 32 reciprocals of a
+// batch were issued BEHIND the look-ahead loads of the batch after next and needed at once -- vmcnt(0), the whole
+// memory latency exposed once per batch (3 of the 8.4 ms of the first update at BASELINE config 3).
+template <int SP /* bucket row stride in floats (even) */>
+__global__ __launch_bounds__(64) void update_chains_pk(const UpdDesc *__restrict__ descs, int k,
+                                                       const float *__restrict__ rcp) {
+  static_assert(SP % 2 == 0 && SP >= 2, "even stride");
+  constexpr int HP = SP / 2;
+  const UpdDescG D = load_desc(descs, blockIdx.x);           // x = problem, y = block of 64 lanes: every problem's longest chains first
+  const int s = D.s;
+  const int t = blockIdx.y * blockDim.x + threadIdx.x;
+  if (t >= k * HP) return;
+  const int slot = t / HP, jp = t - slot * HP, j = 2 * jp;
+  if (j >= s) return;                              // (s + 1) / 2 < HP: a problem narrower than the launch's stride
+  const bool pad = j + 1 >= s;
+  const int c = D.corder ? D.corder[slot] : slot;
+  const unsigned len = D.count[c];
+  if (len == 0) { D.cout[c * s + j] = 0.f; if (!pad) D.cout[c * s + j + 1] = 0.f; return; }
+  const auto col = reinterpret_cast<gptr<const f32x2>>(D.xb + (size_t)D.start[c] * SP + j);
+  auto fix = [pad](f32x2 v) { if (pad) v.y = v.x; return v; };
+  auto slow = [](f32x2 p, f32x2 x, unsigned n1) {
+    const float nf = (float)(int)n1;
+    p.x = p.x + __fdiv_rn(x.x - p.x, nf);
+    p.y = p.y + __fdiv_rn(x.y - p.y, nf);
+    return p;
+  };
+  constexpr int U = 32;
+  f32x2 p = {0.f, 0.f};
+  unsigned i = 0;
+  auto nxt = col;
+  // one batch: the look-ahead loads of the batch after next into `ld`, then the 32 steps of `cur`
+  auto batch = [&](const f32x2 (&cur)[U], f32x2 (&ld)[U]) {
+#ifdef GULON_CHAINS_NOLOAD   // timing experiment (wrong results): the recurrence alone, no loads in the loop
+#pragma unroll
+    for (int u = 0; u < U; u++) ld[u] = cur[u] * 1.0001f;
+#else
+#pragma unroll
+    for (int u = 0; u < U; u++) ld[u] = fix(nxt[(size_t)u * HP]);
+#endif
+    const f32x2 p0 = p;
+    float lo = INFINITY, hi = 0.f;
+    float nf = (float)(int)(i + 1);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const f32x2 a = cur[u] - p;
+      lo = fminf(fminf(lo, fabsf(a.x)), fabsf(a.y));
+      hi = fmaxf(fmaxf(hi, fabsf(a.x)), fabsf(a.y));
+      const float y = rcp[i + u];
+      const f32x2 y2 = {y, y}, nn = {-nf, -nf};
+      const f32x2 q0 = a * y2;
+      const f32x2 r = __builtin_elementwise_fma(nn, q0, a);
+      p = p + __builtin_elementwise_fma(r, y2, q0);
+      nf += 1.0f;                                   // exact below 2^24
+    }
+    // a zero, tiny, huge or NaN numerator somewhere in the batch: the plain division, from the batch's start
+    if (!__all(lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */)) {
+      p = p0;
+#pragma unroll
+      for (int u = 0; u < U; u++) p = slow(p, cur[u], i + u + 1);
+    }
+    i += U;
+    nxt += (size_t)U * HP;
+  };
+  if (len >= 3 * U) {
+    f32x2 xa[U], xb[U], xc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) xa[u] = fix(col[(size_t)u * HP]);
+#pragma unroll
+    for (int u = 0; u < U; u++) xb[u] = fix(col[(size_t)(U + u) * HP]);
+    nxt = col + (size_t)2 * U * HP;
+    // three batches per trip, the buffers taking turns (no register copies); every look-ahead stays inside the cluster
+    while (i + 5 * U <= len) { batch(xa, xc); batch(xb, xa); batch(xc, xb); }
+    while (i + 3 * U <= len) {
+      batch(xa, xc);
+#pragma unroll
+      for (int u = 0; u < U; u++) { xa[u] = xb[u]; xb[u] = xc[u]; }
+    }
+    // the two batches already in registers
+#pragma unroll
+    for (int u = 0; u < U; u++) p = slow(p, xa[u], i + u + 1);
+    i += U;
+#pragma unroll
+    for (int u = 0; u < U; u++) p = slow(p, xb[u], i + u + 1);
+    i += U;
+  }
+  for (; i < len; i++) p = slow(p, fix(col[(size_t)i * HP]), i + 1);
+  D.cout[c * s + j] = p.x;
+  if (!pad) D.cout[c * s + j + 1] = p.y;
 }
 
 // ---------------------------------------------------------------------------
@@ -911,7 +1208,7 @@ static void launch_counting_sort(UpdDesc *d_descs, int np, int n, int k, int sma
   const int sp_max = (smax + 1) & ~1;
   const bool staged = compact && k <= 1024 && sp_max <= 16;
   const size_t shm_hist = sizeof(unsigned) * (size_t)k;
-  const size_t shm_place = staged ? sizeof(unsigned) * (5 * (size_t)k + CHUNK_ROWS + CHUNK_ROWS / 2 + 2) + sizeof(float) * CHUNK_ROWS * (size_t)sp_max
+  const size_t shm_place = staged ? sizeof(unsigned) * (5 * (size_t)k + CHUNK_ROWS + CHUNK_ROWS / 2 + 8) + sizeof(float) * CHUNK_ROWS * (size_t)sp_max
                                   : sizeof(unsigned) * 4 * (size_t)k;
   GULON_UNSUPPORTED(shm_place > 160 * 1024, "internal: counting sort with k = %d needs %zu B of LDS", k, shm_place);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -926,7 +1223,32 @@ static void launch_counting_sort(UpdDesc *d_descs, int np, int n, int k, int sma
                                                                                                        : sort_place<16>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(place), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm_place));
-  hipLaunchKernelGGL(place, dim3((unsigned)nchunks, np), dim3(256), shm_place, st, d_descs, n, k, key_bits);
+  static const bool xcd_env = [] { const char *e = getenv("GULON_PLACE_XCD"); return !e || atoi(e) != 0; }();
+  const int cpx = xcd_env && staged ? (int)ceil_div(nchunks, 8LL) : 0;
+  // (measured slower than one item per workgroup: 8.6 against 5.9 ms -- see the note at sort_place_stream)
+  static const bool stream_env = [] { const char *e = getenv("GULON_PLACE_STREAM"); return e && atoi(e) != 0; }();
+  if (cpx > 0 && stream_env) {
+    auto stream = sort_place_stream<16, 4>;
+#define GULON_PICK(S) if (smax <= S) stream = k <= 256 ? sort_place_stream<S, 1> : sort_place_stream<S, 4>
+    GULON_PICK(14); GULON_PICK(12); GULON_PICK(10); GULON_PICK(8); GULON_PICK(6); GULON_PICK(4);
+#undef GULON_PICK
+    if (smax > 14 && k <= 256) stream = sort_place_stream<16, 1>;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shm_place));
+    int dev = 0, cus = 256, per_cu = 1;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(stream), 256, shm_place));
+    static const int pc_env = [] { const char *e = getenv("GULON_PLACE_PER_CU"); return e ? atoi(e) : 0; }();
+    if (pc_env > 0) per_cu = pc_env;
+    int G = std::max(1, cus / 8) * std::max(1, per_cu);           // resident workgroups per XCD
+    G = (int)std::min<long long>(G, (long long)np * cpx);
+    static const int dbg_env = [] { const char *e = getenv("GULON_PLACE_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(stream, dim3(8u * (unsigned)G), dim3(256), shm_place, st, d_descs, np, n, k, key_bits, cpx, G, dbg_env);
+  } else if (cpx > 0)
+    hipLaunchKernelGGL(place, dim3((unsigned)(8LL * cpx * np)), dim3(256), shm_place, st, d_descs, n, k, key_bits, cpx);
+  else
+    hipLaunchKernelGGL(place, dim3((unsigned)nchunks, np), dim3(256), shm_place, st, d_descs, n, k, key_bits, 0);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -986,7 +1308,15 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
               : update_chains<0>;
   // one wave per workgroup; with more workgroups than SIMDs, 40 KiB of (unused) LDS each keeps four per CU -- one per
   // SIMD at full issue rate -- and the rest, the SHORTEST chains (size order), start as the first ones finish
-  const int chain_blocks = ceil_div((long long)k * smax, 64);
+  // two chains per lane on the packed pipe wherever the stride is a compile-time constant (GULON_CHAINS_PK=0: one per lane)
+  static const bool pk_env = [] { const char *e = getenv("GULON_CHAINS_PK"); return !e || atoi(e) != 0; }();
+  const bool pk = pk_env && one_stride && sp_max <= 16;
+  if (pk) {
+    chains = sp_max == 2 ? update_chains_pk<2> : sp_max == 4 ? update_chains_pk<4> : sp_max == 6 ? update_chains_pk<6>
+           : sp_max == 8 ? update_chains_pk<8> : sp_max == 10 ? update_chains_pk<10> : sp_max == 12 ? update_chains_pk<12>
+           : sp_max == 14 ? update_chains_pk<14> : update_chains_pk<16>;
+  }
+  const int chain_blocks = pk ? ceil_div((long long)k * (sp_max / 2), 64) : ceil_div((long long)k * smax, 64);
   int cus = 256;
   { int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); }
   static const int cap_env = [] { const char *e = getenv("GULON_CHAINS_PER_CU"); return e ? atoi(e) : 4; }();
@@ -994,7 +1324,7 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
   if (cap_env > 0 && (long long)chain_blocks * np > (long long)cap_env * cus) chain_lds = (size_t)(160 * 1024) / cap_env;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chains), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)std::max<size_t>(chain_lds, 1)));
-  hipLaunchKernelGGL(chains, dim3(np, chain_blocks), dim3(64), chain_lds, st, d_descs, k);
+  hipLaunchKernelGGL(chains, dim3(np, chain_blocks), dim3(64), chain_lds, st, d_descs, k, descs[0].rcp);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -30,6 +30,21 @@ struct UpdDesc {
   int ld, from, s;
 };
 
+// the same descriptor as the device uses it: every pointer typed as global memory (see as_global, common.hpp)
+struct UpdDescG {
+  gptr<const int> assign;
+  gptr<unsigned> hist, gtot, count, start;
+  gptr<float> xb, cout;
+  gptr<const float> x;
+  gptr<int> corder;
+  int ld, from, s;
+};
+__device__ __forceinline__ UpdDescG load_desc(const UpdDesc *__restrict__ descs, int i) {
+  const UpdDesc D = descs[i];
+  return UpdDescG{as_global(D.assign), as_global(D.hist), as_global(D.gtot), as_global(D.count), as_global(D.start),
+                  as_global(D.xb), as_global(D.cout), as_global(D.x), as_global(D.corder), D.ld, D.from, D.s};
+}
+
 struct KmeansWorkspace {
   struct HostWords { unsigned flagged; unsigned pad; unsigned long long total; };
   HostWords *host = nullptr;           // pinned: counters copied back asynchronously
