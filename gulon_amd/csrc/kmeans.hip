@@ -401,6 +401,12 @@ __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngrou
 //      per cluster, chunk rows / k slices long -- instead of one scattered 40-byte store per row (12.8 GB in
 //      21 ms against ~5 ms at BASELINE config 3: partial-line stores do not combine).
 // STAGED needs k <= 1024 and sp <= 16 (LDS); otherwise the slices go straight to their positions.
+// Measured and dropped (round 2, commit 0fb1c3a has the kernel): the same placement as a persistent stream -- as many
+// workgroups as the chip holds, each requesting its NEXT chunk before sorting the current one.  Loads and sort alone
+// then take 2.5 ms, but with the stores 8.6 ms against 5.9 ms for this kernel: the stores are what binds -- unaligned
+// 160-byte runs leave at 3.4 TB/s at best (scripts/micro/store_runs.hip; whole aligned 128-byte lines: 5.7 TB/s) --
+// and a workgroup that lives on has to wait for its own stores before it can trust its look-ahead loads (vmcnt counts
+// both, in order), while a workgroup that ends leaves its stores to drain under the next one's loads.
 template <int SMAX /* 0: slices go straight to their positions; else staged, s <= SMAX */>
 __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits,
                                                   int cpx /* > 0: chunks per XCD, 1-D grid */) {
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
       const auto src = D.x + (size_t)r * D.ld + D.from;
       int j = 0;
       for (; j + 2 <= s; j += 2) *reinterpret_cast<gptr<f32x2>>(dst + j) = f32x2{src[j], src[j + 1]};
-      if (j < s) dst[j] = src[j];
+      if (j < s) *reinterpret_cast<gptr<f32x2>>(dst + j) = f32x2{src[j], src[j]};   // odd s: the padding column mirrors the last one
     }
   }
   if (!STAGED) return;
@@ -543,7 +549,9 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
           if (e < total) {
             const int row = (int)(((unsigned)e * rdiv) >> 16);
             const int j = e - row * s;
-            sorted[(size_t)lpos[wave * 256 + row] * sp + j] = vv[c4];
+            float *dstp = sorted + (size_t)lpos[wave * 256 + row] * sp + j;
+            dstp[0] = vv[c4];
+            if (j + 1 == s && sp != s) dstp[1] = vv[c4];   // odd s: the padding column mirrors the last one (update_chains_pk)
           }
         }
       }
@@ -559,197 +567,7 @@ __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ de
   for (int u = tid; u < units; u += 256) {
     const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
     const int part = u - lp * h;
-#ifdef GULON_PLACE_EXPT   // timing experiment (wrong results): the chunk's sorted slices written back contiguously
-    dst2[(size_t)r0 * h + u] = src2[u];
-#else
     dst2[(size_t)dstrow[lp] * h + part] = src2[u];
-#endif
-  }
-}
-
-// The staged placement as a STREAM: the launch holds as many workgroups as the chip keeps resident, each walks its
-// share of the (problem, chunk) items, and the loads of the NEXT item -- slices, keys, bucket bases -- are requested
-// before the current item is sorted and written, so that a workgroup's memory latency passes under its own work
-// (one item per workgroup: load, barrier, sort, barrier, store, each phase waiting for the one before; 8.7 ms at
-// BASELINE config 3, 7.2 with the XCD mapping, both far from the 4 ms the 24.8 GB cost at streaming rate).
-// Items are dealt so that the workgroups of an XCD work on consecutive chunks of one problem at about the same time
-// (see sort_place): item j of XCD x = problem j / cpx, chunk x * cpx + j % cpx; workgroup w of the XCD takes
-// j = w, w + G, w + 2G, ...
-template <int SMAX, int PER_MAX /* clusters per thread in the chunk-local scan: 1 (k <= 256) or 4 (k <= 1024) */>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMAX > 10 ? 2 : 3, SMAX > 10 ? 2 : 3))) void sort_place_stream(
-    const UpdDesc *__restrict__ descs, int np, int n, int k, int key_bits, int cpx, int G, int dbg) {
-  constexpr int NV = SMAX;
-  extern __shared__ unsigned sh[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned *wh = sh;                                  // [4][k] per-wave counts, then running positions
-  unsigned *gpos = sh + 4 * k;                        // [k] bucket position of chunk-local position 0
-  int *dstrow = reinterpret_cast<int *>(sh + 5 * k);  // [CHUNK_ROWS] bucket position of a local position
-  unsigned short *rowof = reinterpret_cast<unsigned short *>(sh + 5 * k + CHUNK_ROWS);   // [CHUNK_ROWS] chunk row at a local position
-  float *raw = reinterpret_cast<float *>(sh + ((5 * k + CHUNK_ROWS + CHUNK_ROWS / 2 + 3) & ~3));   // [CHUNK_ROWS][s] as loaded (+1), 16-byte aligned
-  __shared__ unsigned wave_tot[4];
-  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
-  const int nchunks = (n + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  const int cx = min(cpx, nchunks - xcd * cpx);   // this XCD's chunks: [xcd * cpx, xcd * cpx + cx)
-  if (cx <= 0) return;
-  const int items = np * cx;
-  const int per = (k + 255) / 256;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-
-  struct Item {
-    f32x4 v[NV];
-    int keys[4];
-    unsigned g[PER_MAX][3];   // bucket base of the thread's clusters, as its three terms (added when consumed: no wait here)
-  };
-  // the item's problem: descriptors change once per cpx items, so they are re-read only then
-  int d_prob = -1;
-  UpdDescG D{};
-  auto desc = [&](int prob) { if (prob != d_prob) { D = load_desc(descs, prob); d_prob = prob; } };
-  // requests everything item j needs from memory; nothing is waited for here
-  auto fetch = [&](int j, Item &it) {
-    const int prob = j / cx;
-    const long long chunk = (long long)xcd * cpx + (j - prob * cx);
-    const long long r0 = chunk * CHUNK_ROWS;
-    desc(prob);
-    const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
-    const int s = D.s;
-    const long long wr0 = r0 + wave * 256;
-    const int wrows = (int)max(0ll, min(256ll, r1 - wr0));
-    // whole float4s only, every lane a valid address (clamped: no divergent branches around the loads); the up to
-    // three floats behind them -- the last wave of the last chunk when its rows * s is no multiple of 4 -- are read by
-    // the consumer
-    const auto src4 = reinterpret_cast<gptr<const f32x4>>(D.x + (size_t)wr0 * s);
-    const int nf4 = wrows * s / 4;
-#pragma unroll
-    for (int u = 0; u < NV; u++) {
-      const int f = min(lane + 64 * u, max(nf4 - 1, 0));
-      it.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < s && nf4 > 0 && !(dbg & 8)) it.v[u] = (dbg & 16) ? src4[f] : __builtin_nontemporal_load(&src4[f]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const long long r = wr0 + t * 64 + lane;
-      it.keys[t] = r < r1 ? D.assign[r] : 0;
-    }
-    const long long grp = chunk / SCAN_GROUP;
-#pragma unroll
-    for (int q = 0; q < PER_MAX; q++) {
-      const int c = tid * per + q;
-      const int cc = q < per && c < k ? c : 0;
-      it.g[q][0] = D.start[cc];
-      it.g[q][1] = D.gtot[(size_t)grp * k + cc];
-      it.g[q][2] = D.hist[(size_t)chunk * k + cc];
-    }
-  };
-
-  // vmcnt counts loads and stores together, in order: a wait for the next item's slices that comes AFTER this item's
-  // stores in program order also waits for those stores (8.5 ms; 2.7 ms with the stores taken out).  So the look-ahead
-  // is taken over into `cur` just BEFORE the stores are issued -- requested a whole sort earlier, it has long arrived --
-  // and the stores drain under the next item's sort.
-  Item cur, nxt;
-  if (w < items) { fetch(w, nxt); cur = nxt; }
-  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the loop is entered with nothing pending, as on its back edge
-  for (int j = w; j < items; j += G) {
-    const int prob = j / cx;
-    const long long chunk = (long long)xcd * cpx + (j - prob * cx);
-    const long long r0 = chunk * CHUNK_ROWS;
-    // this item's descriptor fields before the look-ahead moves on to (possibly) the next problem
-    desc(prob);
-    const int s = D.s;
-    const auto xb = D.xb;
-    if (j + G < items) fetch(j + G, nxt);
-    const long long r1 = r0 + CHUNK_ROWS < n ? r0 + CHUNK_ROWS : n;
-    const int sp = (s + 1) & ~1;
-    const long long wr0 = r0 + wave * 256;
-    __syncthreads();                             // the previous item's stage D has read `raw`, `rowof`, `dstrow`
-    for (int e = tid; e < 4 * k; e += 256) wh[e] = 0;
-    // the wave's slices into LDS as they came (row-major, compact): 16 bytes per lane and load, no conflicts
-    if (!(dbg & 2)) {
-      f32x4 *raw4 = reinterpret_cast<f32x4 *>(raw + (size_t)wave * 256 * s);   // 256 * s floats = 64 * s float4
-      const int wrows = (int)max(0ll, min(256ll, r1 - wr0));
-      const int nf4 = wrows * s / 4;
-#pragma unroll
-      for (int u = 0; u < NV; u++)
-        if (u < s && lane + 64 * u < nf4) raw4[lane + 64 * u] = cur.v[u];
-      if (nf4 * 4 < wrows * s) {                  // (rare, uniform) the floats behind the last whole float4
-        const int e = nf4 * 4 + lane;
-        if (e < wrows * s) raw[(size_t)wave * 256 * s + e] = D.x[(size_t)wr0 * s + e];
-      }
-    }
-    __syncthreads();
-    // A: per-wave counts (the lanes holding the same cluster: one ballot per key bit)
-    unsigned long long same[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const bool valid = wr0 + t * 64 + lane < r1;
-      unsigned long long sm = __ballot(valid);
-      for (int bit = 0; bit < key_bits; bit++) {
-        const unsigned long long bm = __ballot((cur.keys[t] >> bit) & 1);
-        sm &= ((cur.keys[t] >> bit) & 1) ? bm : ~bm;
-      }
-      same[t] = valid ? sm : 0ull;
-      if (valid && (sm & lt) == 0ull) wh[wave * k + cur.keys[t]] += (unsigned)__popcll(sm);
-    }
-    __syncthreads();
-    // B: exclusive scan of the chunk's cluster totals; first position of every (cluster, wave)
-    {
-      unsigned mine = 0;
-      for (int c = tid * per; c < min(k, tid * per + per); c++) mine += wh[c] + wh[k + c] + wh[2 * k + c] + wh[3 * k + c];
-      unsigned incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-      }
-      if (lane == 63) wave_tot[wave] = incl;
-      __syncthreads();
-      unsigned base = incl - mine;
-      for (int ww = 0; ww < wave; ww++) base += wave_tot[ww];
-#pragma unroll
-      for (int q = 0; q < PER_MAX; q++) {
-        const int c = tid * per + q;
-        if (q < per && c < k) {
-          const unsigned t0 = wh[c], t1 = wh[k + c], t2 = wh[2 * k + c], t3 = wh[3 * k + c];
-          gpos[c] = cur.g[q][0] + cur.g[q][1] + cur.g[q][2] - base;
-          wh[c] = base; wh[k + c] = base + t0; wh[2 * k + c] = base + t0 + t1; wh[3 * k + c] = base + t0 + t1 + t2;
-          base += t0 + t1 + t2 + t3;
-        }
-      }
-    }
-    __syncthreads();
-    // C: placement (same-wave LDS accesses execute in program order): local position -> bucket position and chunk row
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const bool valid = wr0 + t * 64 + lane < r1;
-      const int key = cur.keys[t];
-      const unsigned b = valid ? wh[wave * k + key] : 0u;
-      const unsigned pos = b + (unsigned)__popcll(same[t] & lt);
-      if (valid && (same[t] & lt) == 0ull) wh[wave * k + key] = b + (unsigned)__popcll(same[t]);
-      if (valid) { dstrow[pos] = (int)(gpos[key] + pos); rowof[pos] = (unsigned short)(wave * 256 + t * 64 + lane); }
-    }
-    __syncthreads();
-    // D: the slices leave in sorted order as float2 units -- consecutive units of a cluster's run are consecutive in
-    // memory; a unit is gathered from its row's place in `raw` (two dwords: rows of an odd s start on odd words; the
-    // padding half of an odd s's last unit reads the neighbouring word, which nobody looks at).  The trip count is a
-    // compile-time constant: the stores of this item must not hide the count of outstanding memory operations from
-    // the wait for the NEXT item's loads at the top of the loop (vmcnt counts both, in order).
-    const int h = sp >> 1;
-    const int units = (int)(r1 - r0) * h;
-    const unsigned hdiv = ((1u << 20) + (unsigned)h - 1u) / (unsigned)h;   // u / h == (u * hdiv) >> 20 for u < 8192, h <= 8
-    const auto dst2 = reinterpret_cast<gptr<f32x2>>(xb);
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), HERE: every load in flight is the look-ahead's
-    cur = nxt;                                   // (nothing below reads `cur`)
-    if (!(dbg & 1)) {
-#pragma unroll
-      for (int it = 0; it < CHUNK_ROWS * ((SMAX + 1) / 2) / 256; it++) {
-        const int u = tid + 256 * it;
-        if (u < units) {
-          const int lp = (int)(((unsigned long long)(unsigned)u * hdiv) >> 20);
-          const int part = u - lp * h;
-          const float *src = raw + (size_t)rowof[lp] * s + 2 * part;
-          dst2[(size_t)dstrow[lp] * h + part] = f32x2{src[0], src[1]};
-        }
-      }
-    }
   }
 }
 
@@ -889,97 +707,108 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
 // register pair at the cost of one instruction, so lane = (cluster, PAIR of dims): 640 waves, one per SIMD, and the
 // per-step instruction stream (5 packed + min3 + max3 + one 8-byte load) is no longer than the scalar one was.
 // The bucket row stride is even (sort_place), so the pair is one aligned 8-byte load; the second half of the last
-// pair of an odd s walks the padding column (whatever sort_place left there): it mirrors the first half instead
-// and is never stored.
-// `rcp` arrives as a kernel argument of its own (every problem shares the device's table): a restrict-qualified
-// argument indexed by the wave-uniform step number becomes scalar loads.  As vector loads the 32 reciprocals of a
-// batch were issued BEHIND the look-ahead loads of the batch after next and needed at once -- vmcnt(0), the whole
-// memory latency exposed once per batch (3 of the 8.4 ms of the first update at BASELINE config 3).
+// pair of an odd s walks the padding column, which sort_place fills with a copy of the last real column: a chain
+// that behaves exactly like its neighbour (same range checks, same path) and is never stored.  (Mirroring it here,
+// one v_cndmask per loaded value, made every load wait for its data at once.)
+// The wave walks its batches in LOCKSTEP: the trip count is the maximum over its lanes and every lane stays active
+// to the end -- a lane whose cluster is exhausted keeps its result aside, re-reads its last batch (in bounds, cached)
+// and is left out of the range test.  That makes the step number wave-uniform with all 64 lanes alive, so the 32
+// reciprocals of a batch can travel like a 33rd column: lane u of `ycur` holds RN(1 / (i + u + 1)), requested two
+// batches ahead by one coalesced load, and every step reads its own with v_readlane; the divisors are converted once
+// per batch the same way.  (As scalar loads they were requested at the top of the batch that needs them and waited
+// for three times per batch -- a third of the time of a wave that has its SIMD to itself; as per-lane vector loads,
+// round 1, they sat behind the look-ahead loads in vmcnt order: 3 of the first update's 8.4 ms at BASELINE config 3.)
+// What the batches leave of a cluster (fewer than three batches) is walked with the plain division at the end.
 template <int SP /* bucket row stride in floats (even) */>
 __global__ __launch_bounds__(64) void update_chains_pk(const UpdDesc *__restrict__ descs, int k,
                                                        const float *__restrict__ rcp) {
   static_assert(SP % 2 == 0 && SP >= 2, "even stride");
   constexpr int HP = SP / 2;
+  constexpr int U = 32;
   const UpdDescG D = load_desc(descs, blockIdx.x);           // x = problem, y = block of 64 lanes: every problem's longest chains first
   const int s = D.s;
   const int t = blockIdx.y * blockDim.x + threadIdx.x;
-  if (t >= k * HP) return;
   const int slot = t / HP, jp = t - slot * HP, j = 2 * jp;
-  if (j >= s) return;                              // (s + 1) / 2 < HP: a problem narrower than the launch's stride
+  const bool valid = t < k * HP && j < s;          // (j >= s: a problem narrower than the launch's stride)
   const bool pad = j + 1 >= s;
-  const int c = D.corder ? D.corder[slot] : slot;
-  const unsigned len = D.count[c];
-  if (len == 0) { D.cout[c * s + j] = 0.f; if (!pad) D.cout[c * s + j + 1] = 0.f; return; }
-  const auto col = reinterpret_cast<gptr<const f32x2>>(D.xb + (size_t)D.start[c] * SP + j);
-  auto fix = [pad](f32x2 v) { if (pad) v.y = v.x; return v; };
+  const int c = valid ? (D.corder ? D.corder[slot] : slot) : 0;
+  const unsigned len = valid ? D.count[c] : 0u;
+  const auto col = reinterpret_cast<gptr<const f32x2>>(D.xb + (valid ? (size_t)D.start[c] * SP + j : (size_t)0));
   auto slow = [](f32x2 p, f32x2 x, unsigned n1) {
     const float nf = (float)(int)n1;
     p.x = p.x + __fdiv_rn(x.x - p.x, nf);
     p.y = p.y + __fdiv_rn(x.y - p.y, nf);
     return p;
   };
-  constexpr int U = 32;
-  f32x2 p = {0.f, 0.f};
-  unsigned i = 0;
-  auto nxt = col;
-  // one batch: the look-ahead loads of the batch after next into `ld`, then the 32 steps of `cur`
-  auto batch = [&](const f32x2 (&cur)[U], f32x2 (&ld)[U]) {
+  // batches of this lane (the look-ahead of two batches stays inside the cluster), and of the wave
+  const unsigned nb = len >= 3 * U ? (len - 3 * U) / U + 1 : 0u;
+  unsigned nb_wave = nb;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nb_wave = max(nb_wave, (unsigned)__shfl_xor((int)nb_wave, o));
+  nb_wave = (unsigned)__builtin_amdgcn_readfirstlane((int)nb_wave);
+  f32x2 p = {0.f, 0.f}, p_keep = {0.f, 0.f};
+  if (nb_wave > 0) {       // some cluster of the wave has >= 96 rows, so 96 rows from the bucket's base are in bounds
+    const int l32 = threadIdx.x & 31;
+    auto nxt = nb > 0 ? col : reinterpret_cast<gptr<const f32x2>>(D.xb);   // lanes without batches read the base rows
+    unsigned i = 0, b = 0;
+    // one batch: the look-ahead loads of the batch after next into `ld`, then the 32 steps of `cur`
+    auto batch = [&](const f32x2 (&cur)[U], float ycur, f32x2 (&ld)[U], float &yld) {
+      const bool live = b < nb;                    // this lane's cluster still has this batch
+      const auto src = nxt + (size_t)(live ? 2 * U * HP : 0);   // (a finished lane re-reads where it stands: inside its cluster)
 #ifdef GULON_CHAINS_NOLOAD   // timing experiment (wrong results): the recurrence alone, no loads in the loop
 #pragma unroll
-    for (int u = 0; u < U; u++) ld[u] = cur[u] * 1.0001f;
+      for (int u = 0; u < U; u++) ld[u] = cur[u] * 1.0001f;
+      yld = ycur;
 #else
 #pragma unroll
-    for (int u = 0; u < U; u++) ld[u] = fix(nxt[(size_t)u * HP]);
+      for (int u = 0; u < U; u++) ld[u] = src[(size_t)u * HP];
+      yld = rcp[i + 2 * U + l32];
 #endif
-    const f32x2 p0 = p;
-    float lo = INFINITY, hi = 0.f;
-    float nf = (float)(int)(i + 1);
+      const f32x2 p0 = p;
+      float lo = INFINITY, hi = 0.f;
+      const float nfv = (float)(int)(i + 1 + l32);
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const f32x2 a = cur[u] - p;
-      lo = fminf(fminf(lo, fabsf(a.x)), fabsf(a.y));
-      hi = fmaxf(fmaxf(hi, fabsf(a.x)), fabsf(a.y));
-      const float y = rcp[i + u];
-      const f32x2 y2 = {y, y}, nn = {-nf, -nf};
-      const f32x2 q0 = a * y2;
-      const f32x2 r = __builtin_elementwise_fma(nn, q0, a);
-      p = p + __builtin_elementwise_fma(r, y2, q0);
-      nf += 1.0f;                                   // exact below 2^24
-    }
-    // a zero, tiny, huge or NaN numerator somewhere in the batch: the plain division, from the batch's start
-    if (!__all(lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */)) {
-      p = p0;
+      for (int u = 0; u < U; u++) {
+        const f32x2 a = cur[u] - p;
+        lo = fminf(fminf(lo, fabsf(a.x)), fabsf(a.y));
+        hi = fmaxf(fmaxf(hi, fabsf(a.x)), fabsf(a.y));
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ycur), u));
+        const float nf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nfv), u));
+        const f32x2 y2 = {y, y}, nn = {-nf, -nf};
+        const f32x2 q0 = a * y2;
+        const f32x2 r = __builtin_elementwise_fma(nn, q0, a);
+        p = p + __builtin_elementwise_fma(r, y2, q0);
+      }
+      // a zero, tiny, huge or NaN numerator somewhere in a live lane's batch: the plain division, from the batch's start
+      if (!__all(!live || (lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */))) {
+        p = p0;
 #pragma unroll
-      for (int u = 0; u < U; u++) p = slow(p, cur[u], i + u + 1);
-    }
-    i += U;
-    nxt += (size_t)U * HP;
-  };
-  if (len >= 3 * U) {
+        for (int u = 0; u < U; u++) p = slow(p, cur[u], i + u + 1);
+      }
+      if (live) { p_keep = p; nxt += (size_t)U * HP; }
+      i += U;
+      b++;
+    };
     f32x2 xa[U], xb[U], xc[U];
+    float ya, yb, yc;
 #pragma unroll
-    for (int u = 0; u < U; u++) xa[u] = fix(col[(size_t)u * HP]);
+    for (int u = 0; u < U; u++) xa[u] = nxt[(size_t)u * HP];
+    ya = rcp[l32];
 #pragma unroll
-    for (int u = 0; u < U; u++) xb[u] = fix(col[(size_t)(U + u) * HP]);
-    nxt = col + (size_t)2 * U * HP;
-    // three batches per trip, the buffers taking turns (no register copies); every look-ahead stays inside the cluster
-    while (i + 5 * U <= len) { batch(xa, xc); batch(xb, xa); batch(xc, xb); }
-    while (i + 3 * U <= len) {
-      batch(xa, xc);
-#pragma unroll
-      for (int u = 0; u < U; u++) { xa[u] = xb[u]; xb[u] = xc[u]; }
-    }
-    // the two batches already in registers
-#pragma unroll
-    for (int u = 0; u < U; u++) p = slow(p, xa[u], i + u + 1);
-    i += U;
-#pragma unroll
-    for (int u = 0; u < U; u++) p = slow(p, xb[u], i + u + 1);
-    i += U;
+    for (int u = 0; u < U; u++) xb[u] = nxt[(size_t)(U + u) * HP];
+    yb = rcp[U + l32];
+    // three batches per trip, the buffers taking turns (no register copies)
+    while (b + 3 <= nb_wave) { batch(xa, ya, xc, yc); batch(xb, yb, xa, ya); batch(xc, yc, xb, yb); }
+    if (b < nb_wave) batch(xa, ya, xc, yc);
+    if (b < nb_wave) batch(xb, yb, xa, ya);
   }
-  for (; i < len; i++) p = slow(p, fix(col[(size_t)i * HP]), i + 1);
-  D.cout[c * s + j] = p.x;
-  if (!pad) D.cout[c * s + j + 1] = p.y;
+  // what the batches left of the cluster: fewer than three batches' worth, from memory, the plain division
+  p = p_keep;
+  for (unsigned i = nb * U; i < len; i++) p = slow(p, col[(size_t)i * HP], i + 1);
+  if (valid) {
+    D.cout[c * s + j] = p.x;
+    if (!pad) D.cout[c * s + j + 1] = p.y;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1225,27 +1054,7 @@ static void launch_counting_sort(UpdDesc *d_descs, int np, int n, int k, int sma
                                 (int)shm_place));
   static const bool xcd_env = [] { const char *e = getenv("GULON_PLACE_XCD"); return !e || atoi(e) != 0; }();
   const int cpx = xcd_env && staged ? (int)ceil_div(nchunks, 8LL) : 0;
-  // (measured slower than one item per workgroup: 8.6 against 5.9 ms -- see the note at sort_place_stream)
-  static const bool stream_env = [] { const char *e = getenv("GULON_PLACE_STREAM"); return e && atoi(e) != 0; }();
-  if (cpx > 0 && stream_env) {
-    auto stream = sort_place_stream<16, 4>;
-#define GULON_PICK(S) if (smax <= S) stream = k <= 256 ? sort_place_stream<S, 1> : sort_place_stream<S, 4>
-    GULON_PICK(14); GULON_PICK(12); GULON_PICK(10); GULON_PICK(8); GULON_PICK(6); GULON_PICK(4);
-#undef GULON_PICK
-    if (smax > 14 && k <= 256) stream = sort_place_stream<16, 1>;
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)shm_place));
-    int dev = 0, cus = 256, per_cu = 1;
-    HIP_CHECK(hipGetDevice(&dev));
-    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(stream), 256, shm_place));
-    static const int pc_env = [] { const char *e = getenv("GULON_PLACE_PER_CU"); return e ? atoi(e) : 0; }();
-    if (pc_env > 0) per_cu = pc_env;
-    int G = std::max(1, cus / 8) * std::max(1, per_cu);           // resident workgroups per XCD
-    G = (int)std::min<long long>(G, (long long)np * cpx);
-    static const int dbg_env = [] { const char *e = getenv("GULON_PLACE_DBG"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(stream, dim3(8u * (unsigned)G), dim3(256), shm_place, st, d_descs, np, n, k, key_bits, cpx, G, dbg_env);
-  } else if (cpx > 0)
+  if (cpx > 0)
     hipLaunchKernelGGL(place, dim3((unsigned)(8LL * cpx * np)), dim3(256), shm_place, st, d_descs, n, k, key_bits, cpx);
   else
     hipLaunchKernelGGL(place, dim3((unsigned)nchunks, np), dim3(256), shm_place, st, d_descs, n, k, key_bits, 0);
