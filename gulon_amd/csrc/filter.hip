@@ -20,6 +20,7 @@
 // The rows go through three filter stages over disjoint, strided sets of row blocks (two short
 // ones that tighten tau, then the rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
 // by the exact scan (per query tile, decided on the device), so the filter never changes a result.
+#include <type_traits>
 #include <map>
 
 #include "scan.hpp"
@@ -284,7 +285,7 @@ template <> struct QEntry<16> { using type = uint4; };
 template <> struct QEntry<8> { using type = uint2; };
 template <> struct QEntry<4> { using type = uint32_t; };
 
-template <int QW, int NQG, int VEC, int NADD, int MAIN>
+template <int QW, int NQG, int VEC, int NADD, int MAIN, int NG1 /* 1: a single code word per row (ng == 1) */>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
     int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap /* entries per sub-queue */,
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   // of up front: 3.21, 3.23, 3.36; five 3.96, eight 5.58 -- the L1 path saturates quickly).  It pays only where
   // LDS is the one busy pipe: 16-byte entries, four entries summed per widening, two workgroups per CU (m <= 16);
   // with 4-byte code words, wider indexes (m = 32, 64, 100) or the 7-bit levels it measured 2-50 % slower.
-  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4) ? 3 : 0;
+#ifndef GULON_FILTER_GLB
+#define GULON_FILTER_GLB 3
+#endif
+  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4 && NG1) ? GULON_FILTER_GLB : 0;
   using Word = typename CodeWord<VEC>::type;
   using QE = typename QEntry<QW>::type;
   extern __shared__ uint4 qlds_raw[];
@@ -350,19 +354,26 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
 #pragma unroll
       for (int x = 0; x < 2 * DW; x++) acc[s][x] = 0;
 
-    for (int g = 0; g < ng; g++) {
+    // one code word (VEC quantizers) of the row block; G0: the index has a single word per row (m <= 16), so the
+    // table offsets are compile-time constants -- an LDS address is then one SDWA shift of the code byte (the entry's
+    // quantizer rides in the instruction's offset field) instead of an extraction and a shift-add
+    auto word = [&](const int g, auto G0) {
       Word wn = w;
-      if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
-      const QE *tj_lds = qlds + g * VEC * 256;
-      const QE *tj_glb = reinterpret_cast<const QE *>(qtab) + (size_t)tile * NQG * tab + g * VEC * 256;
+      if (!decltype(G0)::value && g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
+      const QE *tj_lds = decltype(G0)::value ? qlds : qlds + g * VEC * 256;
       // the L1-served entries are the LAST GLB of the word, requested first: their latency passes under the
-      // LDS gathers of the other entries (byte sums commute)
+      // LDS gathers of the other entries (byte sums commute).  Uniform base (SGPR pair) + 32-bit lane offset: one
+      // instruction per address instead of a 64-bit add chain
+      const uint8_t *tj_glb = qtab + ((size_t)tile * NQG * tab + (decltype(G0)::value ? 0 : g * VEC * 256)) * sizeof(QE);
       QE gl[GLB > 0 ? GLB : 1][NQG];
 #pragma unroll
       for (int a = 0; a < GLB; a++)
 #pragma unroll
-        for (int s = 0; s < NQG; s++)
-          gl[a][s] = tj_glb[(VEC - GLB + a) * 256 + code_byte<VEC>(w, VEC - GLB + a) + s * tab];
+        for (int s = 0; s < NQG; s++) {
+          const uint8_t *base = tj_glb + ((size_t)(VEC - GLB + a) * 256 + (size_t)s * tab) * sizeof(QE);
+          const uint32_t off = code_byte<VEC>(w, VEC - GLB + a) * (uint32_t)sizeof(QE);
+          gl[a][s] = *reinterpret_cast<const QE *>(base + off);
+        }
 #pragma unroll
       for (int b = 0; b < VEC; b += NADD) {
         uint32_t c[NADD];
@@ -379,6 +390,13 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
             if (e >= VEC - GLB) {
 #pragma unroll
               for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&gl[e - (VEC - GLB)][s])[dd];
+            } else if constexpr (decltype(G0)::value && QW == 16) {
+              // the tables sit at LDS address 0 (the kernel has no static LDS; checked by the host at launch): with
+              // a literal base the whole address is  (code byte << 4) + constant  -- one SDWA shift
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const u32x4 y = reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(0)[e * 256 + c[a] + s * tab];
+#pragma unroll
+              for (int dd = 0; dd < DW; dd++) xs[dd] += y[dd];
             } else {
               const QE y = tj_lds[e * 256 + c[a] + s * tab];
 #pragma unroll
@@ -393,7 +411,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
         }
       }
       w = wn;
-    }
+    };
+    if constexpr (NG1) word(0, std::true_type{});
+    else
+      for (int g = 0; g < ng; g++) word(g, std::false_type{});
 
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
@@ -555,7 +576,15 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
                      int from, int until, int cap, bool main_stage, int B, hipStream_t st) {
   const int W_fp32 = ix->w;
   const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW;
-  auto kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1> : filter_kernel<QW, NQG, VEC, NADD, 0>;
+  // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
+  constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
+  auto kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, 0> : filter_kernel<QW, NQG, VEC, NADD, 0, 0>;
+  if (one_word_form && ix->ng == 1) {
+    kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, one_word_form> : filter_kernel<QW, NQG, VEC, NADD, 0, one_word_form>;
+    hipFuncAttributes fa;
+    HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+    GULON_REQUIRE(fa.sharedSizeBytes == 0, "internal: the single-word filter kernel addresses its tables from LDS offset 0");
+  }
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
