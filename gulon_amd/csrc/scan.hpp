@@ -164,6 +164,12 @@ inline const ScanTuning &tuning_of(const gulon_index *ix) { return ix && ix->tun
 void wide_store_codes(gulon_index *ix, const uint16_t *wide16 /* device, [m][n] */);
 void launch_build_tables_wide(const float *cents, const int *from, const int *sdim, int d, int m, int k, const float *dQ,
                               int q0, int nq, float *tables /*[nq][m][k]*/, hipStream_t st);
+// wide_filter.hip: the quantized lower-bound filter for 16-bit code words (k <= 1024 at m = 16)
+bool wide_filter_eligible(const gulon_index *ix, int B, int K, int rb_total);
+void run_wide_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out,
+                           int *d_oi, float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st);
+void launch_scan_wide_range(gulon_index *ix, int B, int K, int from, int until, int rb_begin, int rb_total,
+                            int rb_per_chunk, int nchunks, const int *enable, hipStream_t st);
 void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out, int *d_oi,
                     float *d_od, int *d_oc, int *d_of, float *d_pv, int *d_pi, hipStream_t st);
 

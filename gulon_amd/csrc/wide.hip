@@ -42,25 +42,35 @@ __global__ void relayout_wide(const uint16_t *__restrict__ src /*[m][n]*/, int n
 }
 
 // Index.prepareQuery (Index.scala:352-383) for any k: T[q][j][c] = sum_t (q[from_j + t] - c_j[c][t])^2,
-// t ascending, unfused.  Workgroup = 256 centroids of one (query, quantizer): the query values are
-// block-uniform scalar loads.
+// t ascending, unfused.  Workgroup = 256 centroids of one quantizer x TQ queries: a centroid coordinate is read once
+// for all of them, the query values are block-uniform scalar loads (one workgroup per query: 65 536 workgroups of a
+// few hundred cycles each for a 1024-query batch at k = 1024 -- 0.45 ms; eight queries each: 0.1 ms).
+constexpr int WIDE_TQ = 8;
 __global__ __launch_bounds__(256) void build_tables_wide(const float *__restrict__ cents, const int *__restrict__ from,
                                                          const int *__restrict__ sdim, int d, int m, int k,
-                                                         const float *__restrict__ Q, int q0,
+                                                         const float *__restrict__ Q, int q0, int nq,
                                                          float *__restrict__ T /*[queries of the sub-batch][m][k]*/) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int j = blockIdx.y;
-  const int ql = blockIdx.z;
+  const int ql0 = blockIdx.z * WIDE_TQ;
   if (c >= k) return;
   const int fr = from[j], s = sdim[j];
   const float *cc = cents + (size_t)k * fr + (size_t)c * s;
-  const float *qq = Q + (size_t)(q0 + ql) * d + fr;
-  float acc = 0.f;
+  float acc[WIDE_TQ];
+#pragma unroll
+  for (int u = 0; u < WIDE_TQ; u++) acc[u] = 0.f;
   for (int t = 0; t < s; t++) {
-    const float dd = qq[t] - cc[t];
-    acc += dd * dd;
+    const float cv = cc[t];
+#pragma unroll
+    for (int u = 0; u < WIDE_TQ; u++) {
+      const int ql = min(ql0 + u, nq - 1);                       // (uniform; clamped: always a valid query)
+      const float dd = Q[(size_t)(q0 + ql) * d + fr + t] - cv;
+      acc[u] += dd * dd;
+    }
   }
-  T[((size_t)ql * m + j) * k + c] = acc;
+#pragma unroll
+  for (int u = 0; u < WIDE_TQ; u++)
+    if (ql0 + u < nq) T[((size_t)(ql0 + u) * m + j) * k + c] = acc[u];
 }
 
 // Quantizers [j0, j1) of the table are used by this launch.  LDS_T: that slice is staged in LDS.
@@ -73,8 +83,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void scan_wide(const uint16_t *__rest
                                                           int row_until, int row_base, int rb_begin, int rb_total,
                                                           int rb_per_chunk, int nchunks, int keff,
                                                           float *__restrict__ part_v, int *__restrict__ part_i,
-                                                          int j0, int j1, float *__restrict__ partial) {
+                                                          int j0, int j1, float *__restrict__ partial,
+                                                          const int *__restrict__ enable /* per query; null: all */) {
   extern __shared__ float wide_lds[];
+  if (enable && enable[blockIdx.x] == 0) return;   // (wide_filter.hip: only the queries the filter gave up on)
   if (FIRST) j0 = 0;       // (constants for the optimiser: the one-slice instantiation is the plain scan)
   if (LAST) j1 = m;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,12 +159,28 @@ void wide_store_codes(gulon_index *ix, const uint16_t *wide16) {
 
 void launch_build_tables_wide(const float *cents, const int *from, const int *sdim, int d, int m, int k, const float *dQ,
                               int q0, int nq, float *tables, hipStream_t st) {
-  for (int z0 = 0; z0 < nq; z0 += 32768) {   // grid.z <= 65535
-    const int nz = std::min(32768, nq - z0);
-    hipLaunchKernelGGL(build_tables_wide, dim3(ceil_div(k, 256), m, nz), dim3(256), 0, st, cents, from, sdim, d, m, k, dQ,
-                       q0 + z0, tables + (size_t)z0 * m * k);
+  constexpr int ZMAX = 32768;                      // grid.z <= 65535
+  for (int z0 = 0; z0 < nq; z0 += ZMAX * WIDE_TQ) {
+    const int nz = std::min(ZMAX * WIDE_TQ, nq - z0);
+    hipLaunchKernelGGL(build_tables_wide, dim3(ceil_div(k, 256), m, ceil_div(nz, WIDE_TQ)), dim3(256), 0, st, cents, from,
+                       sdim, d, m, k, dQ, q0 + z0, nz, tables + (size_t)z0 * m * k);
     HIP_CHECK(hipGetLastError());
   }
+}
+
+// The one-slice exact scan (table in LDS) of `B` queries over row blocks [rb_begin, rb_begin + rb_total), rows
+// [from, until): partial lists [B][nchunks * 8][K + 1] into ix->part_v / part_i (wide_filter.hip: its sample scan and
+// its fallback; `enable` selects the queries).  The tables are in ix->tables.
+void launch_scan_wide_range(gulon_index *ix, int B, int K, int from, int until, int rb_begin, int rb_total,
+                            int rb_per_chunk, int nchunks, const int *enable, hipStream_t st) {
+  const size_t lds_bytes = (size_t)ix->m * ix->k * sizeof(float);
+  auto kern = scan_wide<true, true, true>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(B, nchunks), dim3(WIDE_THREADS), lds_bytes, st, ix->wcodes.p, ix->m, ix->k, ix->tables.p,
+                     from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, K + 1, ix->part_v.p,
+                     ix->part_i.p, 0, ix->m, (float *)nullptr, enable);
+  HIP_CHECK(hipGetLastError());
 }
 
 // Table build + scan + merge of one batch over rows [from, until) of a wide index (run_query's contract).
@@ -162,6 +190,10 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
                     ix->k);
   const int keff = K + 1, m = ix->m, k = ix->k;
   const int rb_begin = from / 64, rb_total = ceil_div(until, 64) - rb_begin;
+  if (wide_filter_eligible(ix, B, K, rb_total)) {   // 8-bit lower bounds in front of the exact arithmetic (wide_filter.hip)
+    run_wide_filter_query(ix, dQ, B, K, from, until, final_out, d_oi, d_od, d_oc, d_of, d_pv, d_pi, st);
+    return;
+  }
   const size_t table_bytes = (size_t)m * k * sizeof(float);
   // quantizers per launch: the whole table if it fits LDS; else as many as fit, the running sums going through
   // HBM between the launches; a single quantizer's k entries above 128 KiB (k > 32 768): gathered through L2
@@ -203,7 +235,7 @@ void run_wide_query(gulon_index *ix, const float *dQ, int B, int K, int from, in
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));               \
         hipLaunchKernelGGL(kern, dim3(nq, nchunks), dim3(WIDE_THREADS), lds_bytes, st, ix->wcodes.p, m, k,           \
                            ix->tables.p, from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, keff, \
-                           ix->part_v.p, ix->part_i.p, j0, j1, partial);                                            \
+                           ix->part_v.p, ix->part_i.p, j0, j1, partial, (const int *)nullptr);                      \
       }
       if (!lds_t) WIDE_GO(false, true, true)
       else if (first && last) WIDE_GO(true, true, true)

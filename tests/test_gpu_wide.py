@@ -122,3 +122,89 @@ def test_grouped_index_over_wide_codes(oracle, g, k, strategy, limit):
         assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist()
         assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]]))
     index.close()
+
+
+def _filtered(g, ix):
+    """query tiles of the last batch that went through the 8-bit filter, and of those redone by the exact scan"""
+    import ctypes as C
+    from gulon_amd import native as N
+    t, r = C.c_int32(-1), C.c_int32(-1)
+    N.check(N.lib().gulon_index_filter_stats(ix._h, C.byref(t), C.byref(r)))
+    return t.value, r.value
+
+
+@pytest.mark.parametrize("n,d,m,k,B,K,frm,until", [
+    (40000, 64, 16, 1024, 21, 10, 0, None),         # 8 queries per entry (128 KiB of 8-bit tables)
+    (30000, 32, 8, 257, 9, 1, 0, None),             # smallest wide code book, K = 1
+    (25000, 30, 7, 300, 6, 10, 1234, 20001),        # ragged m (a last group of three quantizers), sub-range
+    (50000, 32, 8, 4096, 13, 63, 0, None),          # 4 queries per entry (128 KiB), largest K
+    (20000, 20, 5, 777, 70, 5, 64, 19999),          # more queries than one launch row, odd k
+    (9000, 16, 16, 2048, 5, 10, 0, None),           # 4 queries per entry at m = 16
+])
+def test_wide_filter_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
+    """The quantized lower-bound filter over 16-bit codes (wide_filter.hip): same ids, order and distance bits as the
+    oracle (and therefore as the exact wide scan), on clustered data where the bounds do prune."""
+    import ctypes as C
+    from gulon_amd import native as N
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n + k)
+    ix = g.PQIndex(pq, enc)
+    N.check(N.lib().gulon_index_tuning(ix._h, b"GULON_FILTER_MIN_RB", 4))     # small ranges through the filter too
+    rng = np.random.default_rng(5)
+    Q = np.concatenate([np.stack([ix.decode(int(r)) for r in rng.integers(0, n, B - 2)]),
+                        rng.standard_normal((2, d))]).astype(np.float32)
+    res = ix.batch_query(K, Q, frm, until)
+    tiles, redone = _filtered(g, ix)
+    assert tiles == B                                            # the batch took the filter ...
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    _check(oracle, res, oi, od, oc)
+    # ... and equals the exact wide scan of the same index
+    N.check(N.lib().gulon_index_tuning(ix._h, b"GULON_SCAN_FILTER", 0))
+    res2 = ix.batch_query(K, Q, frm, until)
+    assert _filtered(g, ix)[0] == 0
+    for a, b in zip(res, res2):
+        assert a.rows.tolist() == b.rows.tolist() and np.array_equal(bits(a.distances), bits(b.distances))
+    ix.close()
+
+
+def test_wide_filter_unusable_bounds_fall_back(oracle, g):
+    """NaN / huge queries (no finite bound) and a tiny survivor queue (every sub-queue overflows): those queries are
+    redone by the exact scan on the device -- results unchanged."""
+    import ctypes as C
+    from gulon_amd import native as N
+    n, d, m, k, B, K = 30000, 32, 8, 1024, 12, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=99)
+    ix = g.PQIndex(pq, enc)
+    N.check(N.lib().gulon_index_tuning(ix._h, b"GULON_FILTER_MIN_RB", 4))
+    N.check(N.lib().gulon_index_tuning(ix._h, b"GULON_FILTER_CAP", 64))      # 4 entries per sub-queue... clamped to 64
+    rng = np.random.default_rng(1)
+    Q = rng.standard_normal((B, d)).astype(np.float32)                       # random queries: loose bounds, many survivors
+    Q[3, 5] = np.float32(3e19)                                               # every distance +inf
+    oi, od, oc, of = ix.batch_query_raw(K, Q)
+    tiles, redone = _filtered(g, ix)
+    assert tiles == B and redone >= 1
+    ei, ed, ec = oracle.pq_batch_query(idx, d, k, cents, Q, K)
+    for q in range(B):
+        if q == 3:
+            continue                                                         # (non-finite distances: the (distance, row) rule on wide indexes)
+        assert np.array_equal(bits(od[q]), bits(ed[q])) and (of[q] & 3 or oi[q].tolist() == ei[q].tolist())
+    ix.close()
+
+
+def test_wide_filter_sharded_equals_unsharded(g):
+    from test_gpu_shared_bounds import _same, sharded_query
+    import ctypes as C
+    from gulon_amd import native as N
+    N.check(N.lib().gulon_scan_tuning(b"GULON_FILTER_MIN_RB", 4))
+    try:
+        n, d, m, k, B, K = 90000, 32, 8, 600, 20, 10
+        rng = np.random.default_rng(8)
+        cents = rng.standard_normal(k * d).astype(np.float32)
+        idx = rng.integers(0, k, (m, n)).astype(np.int32)
+        pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+        coder = pq.coder_factory(n)
+        enc = g.EncodedMatrix(coder, [coder.build_code(idx[j]) for j in range(m)])
+        Q = rng.standard_normal((B, d)).astype(np.float32)
+        full = g.PQIndex(pq, enc).batch_query_raw(K, Q)
+        _same(sharded_query(g, pq, enc, n, 3, Q, K), full)
+    finally:
+        N.check(N.lib().gulon_scan_tuning(b"GULON_FILTER_MIN_RB", 512))
