@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
 
 template <int QW, int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
-                     int from, int until, int cap, bool main_stage, int B, hipStream_t st) {
+                     int from, int until, int cap, bool main_stage, int B, hipStream_t st, int *fb, int qt) {
   const int W_fp32 = ix->w;
   const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW;
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
@@ -589,7 +589,7 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
                                 (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
                      ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
-                     ix->fb_tile.p, W_fp32 * ix->nsub, B);
+                     fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -634,9 +634,10 @@ int filter_nqg(const gulon_index *ix) {
 }
 
 void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
-                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, int B, hipStream_t st) {
+                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, int B, hipStream_t st,
+                   int *fb = nullptr /* tile flags other than the index's own, one per `qt` queries */, int qt = 1) {
 #define GO(W_, Q, V, A) \
-  launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, B, st)
+  launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, B, st, fb, qt)
 #define GO_QV(W_, Q, V) do { if (nadd == 4) GO(W_, Q, V, 4); else GO(W_, Q, V, 2); } while (0)
 #define GO_W(W_) do {                                                  \
     if (ix->vec == 16) { if (nqg == 2) GO_QV(W_, 2, 16); else GO_QV(W_, 1, 16); } \
@@ -646,6 +647,88 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 #undef GO_W
 #undef GO_QV
 #undef GO
+}
+
+// ---- level 2 of the tie replay through the filter (replay_level2_filtered below) ---------------------------------
+// bounds and liveness of the flagged queries: served here iff the batch has enough of them to fill the launch and the
+// query has a finite K-th distance over the earlier rows
+__global__ void rp_filter_bounds(const int *__restrict__ count, int F, int min_flagged, int K,
+                                 const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
+                                 float *__restrict__ tau, int *__restrict__ fb, float *__restrict__ fin_v,
+                                 int *__restrict__ fin_i, int n_pad) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_pad) return;
+  const int nf = min(*count, F);
+  float t = INFINITY;
+  if (f < nf && nf >= min_flagged && prefix_c[f] >= K) t = prefix_v[(size_t)f * K + K - 1];
+  const bool live = t < INFINITY;            // (false for NaN too)
+  tau[f] = live ? t : INFINITY;
+  fb[f] = live ? 0 : 1;
+  fin_v[f] = INFINITY;                       // a one-entry "running list" that never tightens the bound
+  fin_i[f] = INT_MAX;
+}
+
+// the survivors of flagged query f, exactly (the reference's j-ordered unfused sum from the query's fp32 table):
+// those below the bound go to the candidate pool of the literal heap.  A query whose queue overflowed emits nothing
+// and is left to the segment scan.
+template <int VEC>
+__global__ __launch_bounds__(256) void rp_filter_emit(const uint8_t *__restrict__ codes, int ng, int m_pad,
+                                                      const float *__restrict__ tables /*[f][m_pad][256]*/, int row_base,
+                                                      int *__restrict__ cnt, const int *__restrict__ queue, int cap,
+                                                      const int *__restrict__ count, int F, const float *__restrict__ tau,
+                                                      int *__restrict__ fb, float *__restrict__ evv, int *__restrict__ evi,
+                                                      int *__restrict__ evcnt, int pool) {
+  using Word = typename CodeWord<VEC>::type;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  int mine = lane < NSLOT ? cnt[f * NSLOT + lane] : 0;
+  __syncthreads();                                  // every wave has read the counters
+  if (tid < NSLOT) cnt[f * NSLOT + tid] = 0;
+  if (f >= min(*count, F) || fb[f] != 0) return;
+  if (__ballot(mine > cap) != 0ull) {
+    if (tid == 0) fb[f] = 1;                        // a sub-queue overflowed
+    return;
+  }
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < NSLOT; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  const int n = readlane_i(incl, NSLOT - 1);
+  int start[NSLOT];
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; sl++) start[sl] = readlane_i(incl - mine, sl);
+  auto entry = [&](int e) {
+    int sl = 0;
+#pragma unroll
+    for (int x = 1; x < NSLOT; x++) sl += e >= start[x];
+    int off = start[0];
+#pragma unroll
+    for (int x = 1; x < NSLOT; x++) off = sl == x ? start[x] : off;
+    return queue[((size_t)f * NSLOT + sl) * cap + (e - off)];
+  };
+  const float bound = tau[f];
+  const float *tq = tables + (size_t)f * m_pad * 256;
+  const Word *cw = reinterpret_cast<const Word *>(codes);
+  for (int e = tid; e - lane < n; e += 256) {
+    const bool have = e < n;
+    const int row = have ? entry(e) : 0;
+    float d = 0.f;
+    for (int g = 0; g < ng; g++) {
+      const Word w = cw[((size_t)(row >> 6) * ng + g) * 64 + (row & 63)];
+#pragma unroll
+      for (int b = 0; b < VEC; b++) d += tq[(size_t)(g * VEC + b) * 256 + code_byte<VEC>(w, b)];
+    }
+    const bool emit = have && d < bound;            // TopKHeap.update inserts only below its root (strict)
+    const unsigned long long mk = __ballot(emit);
+    if (mk) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&evcnt[f], (int)__popcll(mk));
+      base = readlane_i(base, 0);
+      const int pos = base + (int)__popcll(mk & ((1ull << lane) - 1ull));
+      if (emit && pos < pool) { evv[(size_t)f * pool + pos] = d; evi[(size_t)f * pool + pos] = row + row_base; }
+    }
+  }
 }
 
 }  // namespace
@@ -871,6 +954,55 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
                st);
   if (final_out && replay_enabled()) run_tie_replay(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, flags, st);
   if (final_out && replay_enabled()) run_nonfinite_literal(ix, dQ, B, K, from, until, d_oi, d_od, d_oc, d_of, st);
+}
+
+bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi, int from, int until,
+                            const float *tables, const float *mins, const float *prefix_v, const int *prefix_c,
+                            const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st) {
+  const ScanTuning &t = tuning_of(ix);
+  const int e_count = rb_hi - rb_lo;
+  // (the same conditions as filter_eligible; the byte-code kernels only)
+  if (!t.filter || ix->wide || (size_t)ix->m_pad * 256 * 4 > FILTER_LDS_BUDGET || e_count < t.filter_min_rb || K < 1)
+    return false;
+  const int qw = filter_qw(ix), nqg = filter_nqg(ix);
+  const int nadd = t.filter_nadd ? t.filter_nadd : (ix->m_pad <= 16 ? 4 : 2);
+  const int qmax = 255 / nadd;
+  const int ftiles = ceil_div(F, qw * nqg);
+  const int Fq = ceil_div(ftiles * nqg * qw, 16) * 16;
+  const int cap = std::max(64, t.filter_cap / NSLOT);
+  // a launch is worth its fixed costs (quantisation, table staging of every workgroup) from about two query tiles on
+  const int min_flagged = 2 * qw;
+  ix->rp_fb.ensure((size_t)Fq); ix->rp_fini.ensure((size_t)Fq);
+  ix->rp_tau.ensure((size_t)Fq); ix->rp_finv.ensure((size_t)Fq);
+  ix->qtab.ensure((size_t)Fq * ix->m_pad * 256);
+  ix->sv_cnt.ensure((size_t)Fq * NSLOT);
+  ix->sv_queue.ensure((size_t)Fq * NSLOT * cap);
+  hipLaunchKernelGGL(rp_filter_bounds, dim3(ceil_div(Fq, 256)), dim3(256), 0, st, count, F, min_flagged, K, prefix_v, prefix_c,
+                     ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p, Fq);
+  HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Fq * NSLOT, st));
+  // tables of the flagged queries are [f][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms; queries
+  // beyond F (the padding of the last 16-query group) read no table
+  hipLaunchKernelGGL(qt_quantize, dim3(Fq / 16, ix->m_pad), dim3(256), 0, st, tables, 1, F, ix->m_pad, ix->k, F, mins,
+                     ix->rp_finv.p, ix->rp_fini.p, ix->rp_tau.p, 1, qmax, qw, ix->qtab.p, ix->rp_fb.p, 1);
+  HIP_CHECK(hipGetLastError());
+  const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw;
+  const int resident = std::max(1, std::min(2048 / FILTER_THREADS, (int)(160 * 1024 / filter_lds)));
+  const int slots = device_cus() * resident;
+  const int NW = FILTER_THREADS / 64;
+  int nc = std::max(1, std::min(std::max(ceil_div(slots, ftiles), e_count / 768), std::max(1, e_count / NW)));
+  const int per = ceil_div(e_count, nc);
+  nc = ceil_div(e_count, per);
+  const RbMap all{1, 0, 1};
+  launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_lo, e_count, per, all, from, until, cap, false, F, st, ix->rp_fb.p, 1);
+  if (ix->vec == 16)
+    hipLaunchKernelGGL(rp_filter_emit<16>, dim3(F), dim3(256), 0, st, ix->codes.p, ix->ng, ix->m_pad, tables, ix->row_base,
+                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool);
+  else
+    hipLaunchKernelGGL(rp_filter_emit<4>, dim3(F), dim3(256), 0, st, ix->codes.p, ix->ng, ix->m_pad, tables, ix->row_base,
+                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool);
+  HIP_CHECK(hipGetLastError());
+  *only = ix->rp_fb.p;
+  return true;
 }
 
 }  // namespace gulon

@@ -49,7 +49,8 @@ size_t replay_pack_words(int F, int C) { return 4 + 2 * (size_t)F + 2 * (size_t)
 
 // flagged queries in ascending order (deterministic: every shard builds the same list), the first `skip`
 // of them left out (they were replayed by an earlier round); one wave
-__global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, int B, Pack pk, int skip) {
+__global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, int B, Pack pk, int skip,
+                                                 int *__restrict__ hint /* host-mapped; may be null */) {
   const int lane = threadIdx.x;
   int base = 0;
   for (int q0 = 0; q0 < B; q0 += 64) {
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, 
     if (f >= here) pk.list()[f] = -1;
   }
   if (lane == 0) { pk.count()[0] = here; pk.count()[1] = pk.F; pk.count()[2] = pk.C; pk.count()[3] = base; }
+  if (lane == 0 && hint && skip == 0) *hint = base;
 }
 
 __global__ void rp_gather_queries(const float *__restrict__ Q, int d, int maxf, const int *__restrict__ list,
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
                                                const float *__restrict__ start_v, const int *__restrict__ start_c,
                                                float *__restrict__ out_v, int *__restrict__ out_i,
                                                int *__restrict__ out_c, int pool, float *__restrict__ evv,
-                                               int *__restrict__ evi, int *__restrict__ evcnt) {
+                                               int *__restrict__ evi, int *__restrict__ evcnt,
+                                               const int *__restrict__ only /* per flagged query; null: all */) {
   using Word = typename RpWord<VEC>::type;
   extern __shared__ float tab[];   // m_pad * 256
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
   const int nf = min(*count, maxf);
   // the grid has a fixed, small y extent; each block walks the flagged queries f = y, y+Y, ...
   for (int f = blockIdx.y; f < nf; f += gridDim.y) {
+    if (only && only[f] == 0) continue;     // (uniform) this query's rows came through the quantized filter
     __syncthreads();
     {
       const float *src = tables + (size_t)f * m_pad * 256;
@@ -441,11 +445,23 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
 void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
                     int C, int *pack, hipStream_t st, int skip = 0) {
   const Pack pk{pack, F, C};
-  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, B, pk, skip);
+  // how many queries recent batches of this handle had flagged: read without synchronisation (the word lags by the
+  // batches in flight), it only decides whether the long level is worth the quantized filter's launches -- a batch
+  // with one flagged query (the usual case) pays ~80 us for them, a batch in which every query ties saves 25 ms
+  if (!ix->rp_hint_h) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ix->rp_hint_h), sizeof(int), hipHostMallocMapped));
+    *ix->rp_hint_h = 0;
+    HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ix->rp_hint_d), ix->rp_hint_h, 0));
+  }
+  const int recently_flagged = *reinterpret_cast<volatile int *>(ix->rp_hint_h);
+  hipLaunchKernelGGL(rp_collect, dim3(1), dim3(64), 0, st, d_flags, B, pk, skip, ix->rp_hint_d);
   HIP_CHECK(hipGetLastError());
   if (until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
-  const int gy = std::min(F, 16);   // y extent of the scan grids
+  // y extent of the scan grids (a block walks the flagged queries y, y + Y, ...): the two short levels have few
+  // segments, so every flagged query gets blocks of its own -- a batch in which all 1024 queries tie spent 3.7 ms
+  // in them with 16; the long level keeps 16 (its x extent fills the chip; blocks without a query cost a launch slot)
+  const int gy_short = std::min(F, 256), gy = std::min(F, 16);
   // level geometry (in 64-row blocks)
   const int l0 = std::min(rb_total, RP_L0_BLOCKS);
   const int l1 = std::min(rb_total - l0, RP_L1_BLOCKS);
@@ -459,15 +475,16 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   ix->rp_segcnt.ensure((size_t)F * std::max(segs1, 1));
   ix->rp_l0v.ensure((size_t)F * K); ix->rp_l0i.ensure((size_t)F * K); ix->rp_l0c.ensure(F);
   ix->rp_prefix.ensure((size_t)F * K); ix->rp_precnt.ensure(F);
+  ix->rp_mins.ensure((size_t)(F + 16) * std::max(ix->m_pad, ix->m));
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)F * ix->d, 256)), dim3(256), 0, st, dQ, ix->d, F,
                      pk.list(), pk.count(), ix->rp_q.p);
   if (ix->wide)   // (tables of all F slots: the flagged-query count stays on the device)
     launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->rp_q.p, 0, F, ix->rp_tables.p, st);
   else
-    launch_build_tables(1, ix, ix->rp_q.p, F, F, ix->rp_tables.p, st, pk.count());
+    launch_build_tables(1, ix, ix->rp_q.p, F, F, ix->rp_tables.p, st, pk.count(), ix->rp_mins.p);
   const size_t lds = (size_t)ix->m_pad * 256 * sizeof(float);
   auto scan = [&](int rb_lo, int rb_hi, int per_seg, int nseg, const float *sv, const int *sc, float *ov, int *oi,
-                  int *oc) {
+                  int *oc, int gy, const int *only) {
     if (nseg <= 0) return;
     if (ix->wide) {
       hipLaunchKernelGGL(rp_scan_wide, dim3(ceil_div(nseg, 4), gy), dim3(256), 0, st, ix->wcodes.p, ix->m, ix->k,
@@ -481,19 +498,29 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
                                   (int)lds));
     hipLaunchKernelGGL(kern, dim3(ceil_div(nseg, 4), gy), dim3(256), lds, st, ix->codes.p, ix->ng, ix->m_pad,
                        ix->rp_tables.p, pk.count(), F, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K, sv, sc,
-                       ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt());
+                       ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt(), only);
     HIP_CHECK(hipGetLastError());
   };
   // level 0: cold start over the first rows -> their K smallest distances
-  scan(rb_begin, rb_begin + l0, l0, 1, nullptr, nullptr, ix->rp_l0v.p, ix->rp_l0i.p, ix->rp_l0c.p);
+  scan(rb_begin, rb_begin + l0, l0, 1, nullptr, nullptr, ix->rp_l0v.p, ix->rp_l0i.p, ix->rp_l0c.p, gy_short, nullptr);
   if (segs1 > 0) {
     scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
-         ix->rp_segi.p, ix->rp_segcnt.p);
+         ix->rp_segi.p, ix->rp_segcnt.p, gy_short, nullptr);
     if (segs2 > 0) {
-      hipLaunchKernelGGL(rp_merge, dim3(std::min(F, 64)), dim3(64), 0, st, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
+      hipLaunchKernelGGL(rp_merge, dim3(std::min(F, 1024)), dim3(64), 0, st, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
                          ix->rp_segi.p, pk.count(), F, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
       HIP_CHECK(hipGetLastError());
-      scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr);
+      // The long level.  Its segment scans are an exact fp32 scan of (nearly) all rows per flagged query, one query's
+      // table per workgroup: 27 us per query, 28 ms when all 1024 queries of a batch tie (the reference-shaped data).
+      // With the K-th distance of the earlier rows as a FIXED bound the rows that can insert are a threshold query
+      // -- what the quantized filter answers sixteen queries at a time (the candidates only have to be a superset:
+      // the literal heap applies TopKHeap's own test, in row order); batches with enough flagged queries take that
+      // road, and the segment scan below only walks the queries left to it (`only`).
+      int *only = nullptr;
+      if (recently_flagged >= 32)
+        replay_level2_filtered(ix, F, K, rb_begin + l0 + l1, rb_end, from, until, ix->rp_tables.p, ix->rp_mins.p,
+                             ix->rp_prefix.p, ix->rp_precnt.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only, st);
+      scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr, gy, only);
     }
   }
   if (getenv("GULON_REPLAY_STATS")) {   // debugging aid: synchronous candidate counts
@@ -515,7 +542,7 @@ void replay_apply(const int *packs, int lists, long long stride_words, int F, in
   const size_t heap_lds = (size_t)(2 * lds_pool + 2 * RP_KEEP) * sizeof(float);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rp_heap), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)heap_lds));
-  hipLaunchKernelGGL(rp_heap, dim3(std::min(F, 64)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(F, 1024)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
                      K, d_oi, d_od, d_oc, d_of, dbgp);
   HIP_CHECK(hipGetLastError());
   if (dbgp) {

@@ -54,6 +54,8 @@ struct gulon_index {
   // exact tie replay (replay.hip)
   DevBuf<int> rp_pack, rp_segcnt, rp_segi, rp_precnt, rp_l0i, rp_l0c;
   DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_l0v;
+  DevBuf<int> rp_fb, rp_fini;           // level 2 of the replay through the quantized filter (filter.hip)
+  DevBuf<float> rp_tau, rp_finv, rp_mins;
   // quantized lower-bound filter (filter.hip)
   DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
   DevBuf<int> fin_i, sv_cnt, sv_queue, fb_tile;
@@ -71,6 +73,7 @@ struct gulon_index {
   int pend_b = -1, pend_k = -1, pend_from = -1, pend_until = -1;
   // host-mapped word the filter's fallback launch sets when it had anything to do: sizes the next one
   int *fb_hint_h = nullptr, *fb_hint_d = nullptr;
+  int *rp_hint_h = nullptr, *rp_hint_d = nullptr;   // host-mapped: flagged queries of a recent batch (replay.hip)
   int fb_wide_left = 0;   // launches that stay wide after the word was last seen set
   int last_filter_tiles = 0;   // query tiles of the last filtered batch on this handle (0: it took the exact scan)
   // ---- query contexts (gulon_index_context_create): a context BORROWS the read-only members of its parent
@@ -103,6 +106,7 @@ struct gulon_index {
     for (auto *c : host_all) delete c;
     for (auto &e : ev_pool) (void)hipEventDestroy(e);
     if (fb_hint_h) (void)hipHostFree(fb_hint_h);
+    if (rp_hint_h) (void)hipHostFree(rp_hint_h);
     if (order_ev) (void)hipEventDestroy(order_ev);
     if (host_stream) (void)hipStreamDestroy(host_stream);
   }
@@ -181,6 +185,15 @@ void launch_scan(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e_c
 // merge_lists<false> restricted to the queries of enabled tiles (fallback of the filter)
 void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long long stride_l, long long stride_q, int B,
                           int K, float *out_pv, int *out_pi, const int *tile_enable, int qt, hipStream_t st);
+// filter.hip: level 2 of the tie replay (replay.hip) through the quantized filter.  For the flagged queries f < *count
+// (tables [f][m_pad][256] with their minima `mins`, bounds = the K-th of prefix_v[f][K] when prefix_c[f] >= K) every
+// row of blocks [rb_lo, rb_hi) with an exact distance BELOW the bound is appended to the query's candidate pool
+// (evv / evi / evcnt, `pool` entries per query).  only[f] is left 0 for the queries served here and 1 for those the
+// caller's segment scan still has to do (fewer than `min_flagged` flagged queries, unusable bound, queue overflow).
+// Returns false (nothing enqueued) when this index does not take the filter.
+bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi, int from, int until,
+                            const float *tables, const float *mins, const float *prefix_v, const int *prefix_c,
+                            const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st);
 // filter.hip: sample scan -> quantized filter stages -> exact re-evaluation of the survivors.
 bool filter_eligible(const gulon_index *ix, int K, int rb_total);
 // Bounds shared across row shards (sharded.py): phase 1 stops after the sample scan and writes the K+1

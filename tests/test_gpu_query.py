@@ -134,6 +134,39 @@ def test_exact_heap_replay_whole_batch_flagged(oracle, g):
     ix.close()
 
 
+@pytest.mark.parametrize("n,d,m,k,K,B,nbase,frm,until", [
+    (300000, 32, 8, 256, 10, 100, 400, 0, None),          # every query tied, m = 8 (4-byte code words)
+    (260000, 64, 16, 256, 5, 70, 300, 1000, 255000),      # m = 16 (the headline kernel form), sub-range
+    (200000, 32, 8, 256, 63, 40, 100, 0, None),           # largest K of one scan
+])
+def test_exact_heap_replay_many_flagged_long_range(oracle, g, n, d, m, k, K, B, nbase, frm, until):
+    """Enough flagged queries and rows for the long level of the replay to go through the quantized filter
+    (replay_level2_filtered): half of the rows are copies of a few hundred code rows => hundreds of exact ties for
+    every query; ids and order must be the reference heap's."""
+    rng = np.random.default_rng(n + K)
+    cents = rng.standard_normal(k * d).astype(np.float32)
+    idx = rng.integers(0, k, (m, n)).astype(np.int32)
+    base = rng.integers(0, k, (m, nbase)).astype(np.int32)
+    copies = rng.permutation(n)[:n // 2]
+    idx[:, copies] = base[:, rng.integers(0, nbase, n // 2)]
+    pq = g.ProductQuantizer.from_flat(k, d, m, cents)
+    coder = pq.coder_factory(n)
+    enc = g.EncodedMatrix(coder, [coder.build_code(idx[j]) for j in range(m)])
+    ix = g.PQIndex(pq, enc)
+    Q = np.stack([ix.decode(int(r)) for r in copies[:B]]).astype(np.float32)
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    # twice: the handle takes the filtered road once it has SEEN a batch with many flagged queries (a host-mapped
+    # hint); the first batch goes through the segment scans, the second through the filter -- same answers
+    for _ in range(2):
+        oi_g, od_g, oc_g, of_g = ix.batch_query_raw(K, Q, frm, until)
+        assert np.array_equal(oc_g, oc) and np.array_equal(bits(od_g), bits(od))
+        assert ((of_g & 3) != 0).sum() >= 32                        # enough flagged queries for the filtered level
+        replayed = (of_g & 4) != 0
+        assert replayed[(of_g & 3) != 0].all()
+        assert np.array_equal(oi_g[replayed | (of_g == 0)], oi[replayed | (of_g == 0)])
+    ix.close()
+
+
 @pytest.mark.parametrize("n,d,m,k,B,K,frm,until", [(50000, 64, 16, 256, 5, 64, 0, None), (50000, 64, 16, 256, 3, 100, 0, None),
                                                    (30000, 32, 8, 256, 2, 1000, 100, 29000), (500, 16, 4, 256, 2, 700, 0, None),
                                                    (20000, 40, 10, 256, 9, 127, 0, None), (20000, 40, 10, 256, 2, 128, 0, None)])
