@@ -26,7 +26,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_B
   n=pmc_filter_$(echo $grp | tr ' ' '_' | cut -c1-40)
   pmc $n "$grp" python3 $root/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-recall --no-extras
 done
-(cd "$root" && python3 scripts/pmc_summary.py "filter_kernel<16, 1, 16, 4, 1>" $out/pmc_filter_* > "$out/filter_kernel_pmc.csv")
+(cd "$root" && python3 scripts/pmc_summary.py "filter_kernel<16, 1, 16, 4, 1, 1>" $out/pmc_filter_* > "$out/filter_kernel_pmc.csv")
 cat "$out/filter_kernel_pmc.csv"
 # 2. the exact scan (filter off)
 GULON_SCAN_FILTER=0 stats bench_exact_scan python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall --no-extras
@@ -39,4 +39,8 @@ cat "$out/kmeans_c3_assign_pmc.csv"
 # 4. GroupedIndex, 10 M rows
 stats grouped_10M python3 $root/tests/perf/bench_grouped.py 10000000
 (cd "$root" && python3 tests/perf/bench_grouped.py 10000000 2>/dev/null | tail -1 > "$out/bench_grouped_10M.json"; python3 tests/perf/bench_grouped.py 1000000 2>/dev/null | tail -1 > "$out/bench_grouped_1M.json")
+# 5. wide codes (k = 1024) through the quantized filter, and the reference-shaped data (every query an exact tie)
+stats wide_1M_k1024 python3 $root/tests/perf/bench_wide.py
+(cd "$root" && python3 tests/perf/bench_wide.py 2>/dev/null | tail -1 > "$out/bench_wide_1M_k1024.json"; GULON_SCAN_FILTER=0 python3 tests/perf/bench_wide.py 2>/dev/null | tail -1 > "$out/bench_wide_1M_k1024_exact.json")
+stats bench_kind1 python3 $root/bench.py --steps 5 --warmup 2 --inflight 1 --data-kind 1 --no-cpu-baseline --no-recall --no-extras
 echo done
