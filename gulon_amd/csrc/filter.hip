@@ -20,8 +20,9 @@
 // The rows go through three filter stages over disjoint, strided sets of row blocks (two short
 // ones that tighten tau, then the rest).  A query whose bound is unusable (NaN/inf) or whose survivor queue overflows is redone
 // by the exact scan (per query tile, decided on the device), so the filter never changes a result.
-#include <type_traits>
+#include <atomic>
 #include <map>
+#include <type_traits>
 
 #include "scan.hpp"
 
@@ -597,25 +598,38 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
 // different streams) cannot usefully overlap -- they would only time-slice and blur each other's
 // duration.  Launches are therefore chained through one event per device: a batch's small,
 // latency-bound kernels overlap with another batch's filter, the filters themselves run in turn.
-struct FilterLane {
-  std::mutex mu;
-  std::map<int, hipEvent_t> ev;   // device -> completion of the most recent filter launch
+struct FilterLane {   // per device: completion of the most recent main-stage launch (created on first use, never destroyed)
+  static constexpr int MAX_DEVICES = 64;
+  std::atomic<hipEvent_t> ev[MAX_DEVICES];
+  FilterLane() { for (auto &e : ev) e.store(nullptr, std::memory_order_relaxed); }
+  // the device's event; `fresh` = this call created it (nothing to wait for yet).  Lock-free after the first launch
+  // on a device: the launch path of every batch of every index goes through here.
+  hipEvent_t of(int dev, bool &fresh) {
+    fresh = false;
+    GULON_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device ordinal %d out of range", dev);
+    hipEvent_t e = ev[dev].load(std::memory_order_acquire);
+    if (e) return e;
+    hipEvent_t mine = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&mine, hipEventDisableTiming));
+    if (ev[dev].compare_exchange_strong(e, mine, std::memory_order_acq_rel)) { fresh = true; return mine; }
+    (void)hipEventDestroy(mine);            // another thread was first
+    return e;
+  }
 };
 FilterLane &filter_lane() { static FilterLane l; return l; }
 
-int device_cus() {   // compute units of the current device
-  static std::map<int, int> cus;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
+int device_cus() {   // compute units of the current device (cached per ordinal, lock-free)
+  static std::atomic<int> cus[FilterLane::MAX_DEVICES];
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
-  auto it = cus.find(dev);
-  if (it == cus.end()) {
-    int n = 0;
+  GULON_REQUIRE(dev >= 0 && dev < FilterLane::MAX_DEVICES, "device ordinal %d out of range", dev);
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    it = cus.emplace(dev, std::max(1, n)).first;
+    n = std::max(1, n);
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return it->second;
+  return n;
 }
 
 // queries per quantized table entry: as many as LDS holds for one group (16 up to m_pad = 36,
@@ -876,21 +890,16 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       ev1 = ix->take_event();
     }
     {
-      FilterLane &ln = filter_lane();
-      std::lock_guard<std::mutex> lock(ln.mu);
       int dev = 0;
       HIP_CHECK(hipGetDevice(&dev));
-      auto it = ln.ev.find(dev);
-      if (it == ln.ev.end()) {
-        hipEvent_t e = nullptr;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        it = ln.ev.emplace(dev, e).first;
-      } else if (main_stage) {
-        HIP_CHECK(hipStreamWaitEvent(st, it->second, 0));   // only the main stage takes turns
-      }
+      bool fresh = false;
+      const hipEvent_t lane_ev = filter_lane().of(dev, fresh);
+      // only the main stage takes turns.  (Two host threads enqueueing at the same instant may both wait for the SAME
+      // earlier launch and then share the chip once: the event orders launches for throughput, never for results.)
+      if (main_stage && !fresh) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
       launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage, B, st);
-      if (main_stage) HIP_CHECK(hipEventRecord(it->second, st));
+      if (main_stage) HIP_CHECK(hipEventRecord(lane_ev, st));
     }
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
       HIP_CHECK(hipStreamSynchronize(st));
