@@ -1102,6 +1102,7 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
     for (const UpdDesc &D : descs) kmeans_update_bigk(D, d_descs, n, k, st);
     return;
   }
+  if (kmeans_update_fused(descs, d_descs, n, k, st)) return;   // chains straight from the unsorted slices (kmeans_fused.hip)
   HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
   int smax = 1;
   for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
@@ -1306,7 +1307,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, pr.st));
     pr.use_mfma = mfma_assign_supported(s, k);
     if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, k, pr.packed, pr.st);
-    pr.xs.alloc((size_t)n * s);
+    pr.xs.alloc((size_t)n * s + 2);   // (+2: update_fused reads rows as pairs of floats)
     GULON_UNSUPPORTED((long long)n * s >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items",
                       (long long)n * s);
     hipLaunchKernelGGL(copy_slice, dim3(ceil_div((long long)n * s, 256)), dim3(256), 0, pr.st, dX, ld, from[p], s,

@@ -1,6 +1,7 @@
 // Internal declarations for the KMeans kernels' host drivers.
 #pragma once
 #include <cfloat>
+#include <vector>
 
 #include "common.hpp"
 
@@ -104,6 +105,8 @@ void assign_stage3(AssignJob &j);
 // exact re-check of the flagged rows; without it every row takes the exact VALU kernel.
 void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
                        int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps = nullptr);
+// kmeans_fused.hip: KMeans.fromAssignment without the regrouped copy (false: the shape keeps the bucketed path)
+bool kmeans_update_fused(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st);
 void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
                        const int *d_assign, float *dC, hipStream_t st);
 

@@ -387,6 +387,9 @@ __global__ __launch_bounds__(256) void assign_mfma_stream(const float *__restric
 // bit-identical to the reference whatever the matrix cores round like (gulon_selftest_assign_band measures the
 // band's margin on the hardware).
 // ---------------------------------------------------------------------------------------------
+#ifndef GULON_BF16_WAVES
+#define GULON_BF16_WAVES
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float f) {   // round to nearest even; finite inputs
@@ -461,7 +464,7 @@ __global__ void pack_centroids_split(const float *__restrict__ C, const float *_
 
 // probe != nullptr (one workgroup, selftest): the raw d' of the first tile pair against centroid block 0 go to
 // probe[64 rows][32 centroids] and nothing else is written
-__global__ __launch_bounds__(256) void assign_bf16(const uint4 *__restrict__ xq, const float *__restrict__ xn, int n,
+__global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 *__restrict__ xq, const float *__restrict__ xn, int n,
                                                    long long npairs, const uint4 *__restrict__ apack,
                                                    const float *__restrict__ offp, int nkb,
                                                    const unsigned *__restrict__ cmax2_bits, float errk,

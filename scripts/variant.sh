@@ -7,7 +7,7 @@ mkdir -p build/expt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall \
   -Wno-unused-function -Iinclude "$@" -c gulon_amd/csrc/$stem.hip -o build/expt/${stem}_$tag.o
 objs=""
-for f in api_core scan knn kmeans kmeans_mfma replay filter grouped wide wide_filter sharded literal; do
+for f in api_core scan knn kmeans kmeans_fused kmeans_mfma replay filter grouped wide wide_filter sharded literal; do
   if [ $f = $stem ]; then objs="$objs build/expt/${stem}_$tag.o"; else objs="$objs build/obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/expt/libgulon_$tag.so $objs -ldl

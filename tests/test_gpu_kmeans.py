@@ -219,3 +219,29 @@ def test_bf16_split_filter_error_stays_inside_its_band(g, s):
         g.native.check(g.native.lib().gulon_selftest_assign_band(s, seed, scale, C.byref(r)))
         worst = max(worst, r.value)
     assert 0.0 <= worst < 0.5, worst
+
+
+def test_fused_update_experiment_is_bit_exact():
+    """kmeans_fused.hip (KMeans.fromAssignment without the regrouped copy; off by default, GULON_UPDATE_FUSED=1):
+    the training loop through it, in a child process (the switch is read once per process), against the oracle --
+    ragged sub-dimensions (odd s: the mirrored padding column), k not a multiple of the clusters per workgroup,
+    n not a multiple of the chunk, duplicated rows (the plain-division path), a one-chunk problem."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import gulon_amd as g
+        from oracle import oracle
+        def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
+        for n, d, m, k, iters, dup in [(30000, 50, 7, 256, 3, 0), (20500, 27, 3, 37, 2, 5000), (900, 12, 4, 16, 2, 0),
+                                       (41000, 128, 8, 200, 2, 0)]:
+            X = oracle.synth(n, d, 3, 11 + n, 40)
+            if dup: X[-dup:] = X[:dup]
+            pq = g.ProductQuantizer.apply(g.DeviceMatrix.from_host(X), g.ProductQuantizerConfig(k, m, iters))
+            cents, _, _ = oracle.pq_train(X, m, k, iters)
+            assert np.array_equal(bits(pq.flat_centroids()), bits(cents)), (n, d, m, k)
+        print("fused ok")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, GULON_UPDATE_FUSED="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
