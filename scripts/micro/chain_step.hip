@@ -19,7 +19,7 @@ __device__ __forceinline__ float q3(float a, float nf, float y) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k(float *out, const float *__restrict__ rcp, int steps, unsigned long long *cyc) {
+__global__ __launch_bounds__(256) void k(float *out, const float *__restrict__ rcp, int steps, unsigned long long *cyc) {
   const float x0 = threadIdx.x * 0.37f + 1.0f, x1 = x0 * 1.7f, x2 = x0 * 0.3f, x3 = x0 * 2.9f;
   float p0 = 0, p1 = 0, p2 = 0, p3 = 0;
   f32x2 pp = {0.f, 0.f};
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(64) void k(float *out, const float *__restrict__ rc
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * 64 + threadIdx.x] = p0 + p1 + p2 + p3 + pp.x + pp.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = p0 + p1 + p2 + p3 + pp.x + pp.y;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 int main() {
   const int steps = 1 << 16, blocks = 1024;
   float *out, *rcp; unsigned long long *cyc;
-  CK(hipMalloc(&out, blocks * 64 * 4)); CK(hipMalloc(&rcp, steps * 4)); CK(hipMalloc(&cyc, blocks * 8));
+  CK(hipMalloc(&out, blocks * 256 * 4)); CK(hipMalloc(&rcp, steps * 4)); CK(hipMalloc(&cyc, blocks * 8));
   float *h = (float *)malloc(steps * 4);
   for (int i = 0; i < steps; i++) h[i] = 1.0f / (float)(i + 1);
   CK(hipMemcpy(rcp, h, steps * 4, hipMemcpyHostToDevice));
@@ -81,6 +81,23 @@ int main() {
     for (int b = 0; b < blocks; b++) avg += (double)hc[b];
     avg /= blocks;
     printf("mode %d: %.3f ms, %.1f s_memtime ticks per step (%.1f ns per step)\n", mode, ms, avg / steps, ms * 1e6 / steps);
+  }
+  // Where do the waves of ONE workgroup go?  256 blocks of 256 threads (four waves, 150 KiB of LDS: one block per CU)
+  // against the 1024 one-wave blocks above: the same per-step time means one wave per SIMD in both.
+  {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 150 * 1024, 0, out, rcp, steps, cyc);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    CK(hipMemcpy(hc, cyc, 256 * 8, hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (int b = 0; b < 256; b++) avg += (double)hc[b];
+    printf("mode 1, four-wave workgroups (one per CU): %.3f ms, %.1f ticks per step\n", ms, avg / 256 / steps);
   }
   return 0;
 }
