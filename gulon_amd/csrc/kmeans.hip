@@ -1239,7 +1239,11 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     DevBuf<float> c_prev, c_next;
     DevBuf<int> a_prev, a_next, d_rows;
     DevBuf<unsigned> mism;
-    std::vector<float> h_prev, h_next;
+    // host copies of the centroids and of the mismatch counter: PINNED, so that the per-iteration downloads of all
+    // problems are truly asynchronous (into pageable memory every hipMemcpyAsync stages and blocks: 64 of them were
+    // most of the "convergence test" stage)
+    float *h_prev = nullptr, *h_next = nullptr;
+    unsigned *h_mism = nullptr;
     PackedSlice packed;      // MFMA-ready copy of this problem's column slice
     DevBuf<float> xs;        // row-major n x s copy of the slice: compact target of the update's gathers
     AssignJob job;
@@ -1247,7 +1251,12 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     bool done = false;
     bool shared_stream = false;
     int nrep = 0;
-    ~Prob() { if (st && !shared_stream) (void)hipStreamDestroy(st); }
+    ~Prob() {
+      if (st && !shared_stream) (void)hipStreamDestroy(st);
+      if (h_prev) (void)hipHostFree(h_prev);
+      if (h_next) (void)hipHostFree(h_next);
+      if (h_mism) (void)hipHostFree(h_mism);
+    }
   };
   std::vector<Prob> P(np);
   auto push_report = [&](int p, const gulon_kmeans_report &r) {
@@ -1261,7 +1270,9 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     j.ws = &pr.ws; j.dX = dX; j.n = n; j.ld = ld; j.from = from[p]; j.s = sdim[p]; j.dC = dC; j.k = k;
     j.rng_batch = 25000; j.d_assign = d_assign; j.st = pr.st; j.ps = pr.use_mfma ? &pr.packed : nullptr;
   };
-  // run stages 2 and 3 of every listed problem, one synchronisation round per stage
+  // run stages 2 and 3 of every listed problem, one synchronisation round per stage.  (Measured and dropped: a few
+  // host threads issuing the ~300 short launches of these stages side by side -- 4.3 ms against 4.1 ms with one: the
+  // stage is not bound by the host's launch rate.)
   auto finish_assigns = [&](const std::vector<int> &act) {
     for (int stage = 2; stage <= 3; stage++) {
       bool pending = false;
@@ -1294,7 +1305,9 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
     pr.a_prev.alloc(n); pr.a_next.alloc(n);
     pr.mism.alloc(1);
-    pr.h_prev.resize((size_t)k * s); pr.h_next.resize((size_t)k * s);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_prev), sizeof(float) * (size_t)k * s));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_next), sizeof(float) * (size_t)k * s));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_mism), sizeof(unsigned)));
     // KMeans.init (KMeans.scala:188-196)
     std::vector<int> rows(k);
     JRandom rng((int64_t)seeds[p]);
@@ -1319,7 +1332,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
   lap("alloc+pack+stage1");
   finish_assigns(all);
   for (int p = 0; p < np; p++) {
-    P[p].c_prev.download(P[p].h_prev.data(), (size_t)k * sdim[p], P[p].st);
+    P[p].c_prev.download(P[p].h_prev, (size_t)k * sdim[p], P[p].st);
     HIP_CHECK(hipStreamSynchronize(P[p].st));
   }
   lap("first assign done");
@@ -1361,22 +1374,21 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
         tt.mfma_flops += fm; tt.update_bytes += ub;
       }
     }
-    std::vector<unsigned> h_mism(np, 0);
     for (int p : act) {
       Prob &pr = P[p];
       HIP_CHECK(hipMemsetAsync(pr.mism.p, 0, sizeof(unsigned), pr.st));
       hipLaunchKernelGGL(count_mismatch, dim3(ceil_div(n, 256)), dim3(256), 0, pr.st, pr.a_prev.p, pr.a_next.p, n,
                          pr.mism.p);
-      pr.c_next.download(pr.h_next.data(), (size_t)k * sdim[p], pr.st);
-      pr.mism.download(&h_mism[p], 1, pr.st);
+      pr.c_next.download(pr.h_next, (size_t)k * sdim[p], pr.st);
+      pr.mism.download(pr.h_mism, 1, pr.st);
     }
     for (int p : act) HIP_CHECK(hipStreamSynchronize(P[p].st));
     bool all_conv = true;
     for (int p : act) {
       Prob &pr = P[p];
-      bool converged = h_mism[p] == 0;                       // Arrays.equals(prev, next)
+      bool converged = *pr.h_mism == 0;                      // Arrays.equals(prev, next)
       gulon_kmeans_report r{i, converged ? 1 : 0, 0, 0.f, 0.f};
-      step_stats(pr.h_prev.data(), pr.h_next.data(), k, sdim[p], &r);
+      step_stats(pr.h_prev, pr.h_next, k, sdim[p], &r);
       push_report(p, r);
       std::swap(pr.c_prev, pr.c_next);
       std::swap(pr.a_prev, pr.a_next);
@@ -1388,7 +1400,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     i++;
   }
   for (int p = 0; p < np; p++) {
-    memcpy(c_out[p], P[p].h_prev.data(), sizeof(float) * (size_t)k * sdim[p]);
+    memcpy(c_out[p], P[p].h_prev, sizeof(float) * (size_t)k * sdim[p]);
     if (n_reports) n_reports[p] = P[p].nrep;
   }
 }
