@@ -229,6 +229,25 @@ __global__ void collect_tie_rows(const unsigned *__restrict__ ties, const int *_
   if (ties[i] != 0) list[atomicAdd(count, 1u)] = i;
 }
 
+// Stream positions of a FEW drawing rows without the dense per-row arrays: row i's draws start after those of the
+// drawing rows before it in its segment.  (The dense form -- zero a 40 MB array, scatter the flagged rows' counts,
+// copy, block sums, block scan -- moves 120 MB per problem and iteration for, typically, 70 drawing rows.)
+__global__ void tie_positions_sparse(const unsigned *__restrict__ ties, const int *__restrict__ list,
+                                     const unsigned *__restrict__ count, int seg_len,
+                                     unsigned long long *__restrict__ pos) {
+  const unsigned total = *count;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = list[e], seg = i / seg_len;
+  unsigned long long p = 0;
+  for (unsigned o = 0; o < total; o++) {
+    const int r = list[o];
+    if (r < i && r / seg_len == seg) p += ties[r];
+  }
+  pos[e] = p;
+}
+
+// pos != null: the stream position of list[e] is pos[e] (tie_positions_sparse); else block_off / local (dense form)
 __global__ __launch_bounds__(64) void assign_resolve_wave(const float *__restrict__ X, int ld, int from, int s,
                                                           const float *__restrict__ Cpad, int smax,
                                                           const float *__restrict__ off, int k,
@@ -236,7 +255,8 @@ __global__ __launch_bounds__(64) void assign_resolve_wave(const float *__restric
                                                           const unsigned long long *__restrict__ block_off,
                                                           int seg_len, int bps, const int *__restrict__ list,
                                                           const unsigned *__restrict__ count,
-                                                          int *__restrict__ assign) {
+                                                          int *__restrict__ assign,
+                                                          const unsigned long long *__restrict__ pos) {
   extern __shared__ float rowv[];   // s
   const int lane = threadIdx.x;
   const unsigned total = *count;
@@ -248,7 +268,7 @@ __global__ __launch_bounds__(64) void assign_resolve_wave(const float *__restric
     const int seg = i / seg_len;
     const int blk = (i - seg * seg_len) / 1024;
     JRandom rng(0);
-    rng.skip(block_off[(size_t)seg * bps + blk] + local[i]);
+    rng.skip(pos ? pos[e] : block_off[(size_t)seg * bps + blk] + local[i]);
     float mn = FLT_MAX;
     int best = -1;
     for (int c0 = 0; c0 < k; c0 += 64) {
@@ -904,10 +924,27 @@ void assign_stage1(AssignJob &j) {
 
 // stage 2 (after a stream sync): exact scan of the flagged rows, or -- unfiltered -- the
 // tie replay
-static void launch_tie_replay(AssignJob &j) {
+constexpr unsigned long long SPARSE_TIE_DRAWS = 8192;   // up to this many draws the positions come from the drawing rows alone
+
+static void launch_tie_replay(AssignJob &j, bool sparse = false) {
   KmeansWorkspace &ws = *j.ws;
   const int n = j.n, smax = pick_smax(j.s);
   const int seg_len = j.rng_batch > 0 ? j.rng_batch : n;
+  if (sparse) {   // (filtered jobs, wave-per-row replay: ws.ties holds the flagged rows' counts, indexed by row)
+    ws.tie_rows.ensure((size_t)std::max(j.nrows, 1));
+    ws.tie_count.ensure(1);
+    ws.tie_pos.ensure((size_t)SPARSE_TIE_DRAWS);
+    HIP_CHECK(hipMemsetAsync(ws.tie_count.p, 0, sizeof(unsigned), j.st));
+    hipLaunchKernelGGL(collect_tie_rows, dim3(ceil_div(j.nrows, 256)), dim3(256), 0, j.st, ws.ties.p, j.rows, j.nrows,
+                       ws.tie_rows.p, ws.tie_count.p);
+    hipLaunchKernelGGL(tie_positions_sparse, dim3((unsigned)ceil_div((long long)SPARSE_TIE_DRAWS, 256LL)), dim3(256), 0, j.st,
+                       ws.ties.p, ws.tie_rows.p, ws.tie_count.p, seg_len, ws.tie_pos.p);
+    hipLaunchKernelGGL(assign_resolve_wave, dim3(256), dim3(64), sizeof(float) * (size_t)j.s, j.st, j.dX, j.ld, j.from,
+                       j.s, ws.cpad.p, smax, ws.off.p, j.k, (const unsigned *)nullptr, (const unsigned long long *)nullptr,
+                       seg_len, 0, ws.tie_rows.p, ws.tie_count.p, j.d_assign, ws.tie_pos.p);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int nseg = ceil_div(n, seg_len);
   const int bps = ceil_div(seg_len < n ? seg_len : n, 1024);
   ws.block_tot.ensure((size_t)nseg * bps);
@@ -925,7 +962,7 @@ static void launch_tie_replay(AssignJob &j) {
                        ws.tie_rows.p, ws.tie_count.p);
     hipLaunchKernelGGL(assign_resolve_wave, dim3(1024), dim3(64), sizeof(float) * (size_t)j.s, j.st, j.dX, j.ld, j.from,
                        j.s, ws.cpad.p, smax, ws.off.p, j.k, ws.local.p, ws.block_off.p, seg_len, bps, ws.tie_rows.p,
-                       ws.tie_count.p, j.d_assign);
+                       ws.tie_count.p, j.d_assign, (const unsigned long long *)nullptr);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -956,7 +993,9 @@ void assign_stage3(AssignJob &j) {
   if (j.done) return;
   KmeansWorkspace &ws = *j.ws;
   ws.last_draws = ws.host->total;
-  if (ws.host->total) {
+  if (ws.host->total && ws.host->total <= SPARSE_TIE_DRAWS && (long long)j.k * j.s >= 1024) {
+    launch_tie_replay(j, true);     // few draws: positions from the drawing rows themselves
+  } else if (ws.host->total) {
     // draw counts exist only for the flagged rows: build the dense per-row array (0 elsewhere)
     HIP_CHECK(hipMemsetAsync(ws.local.p, 0, sizeof(unsigned) * (size_t)j.n, j.st));
     hipLaunchKernelGGL(scatter_ties, dim3(ceil_div(j.nrows, 256)), dim3(256), 0, j.st, j.rows, j.nrows, ws.ties.p,

@@ -64,6 +64,7 @@ struct KmeansWorkspace {
   DevBuf<float> apack, offp;
   DevBuf<unsigned> cmax2, flag_count, flag_ties, tie_count;
   DevBuf<int> flag_rows, tie_rows;
+  DevBuf<unsigned long long> tie_pos;  // stream positions of the drawing rows (sparse tie replay)
   unsigned long long last_draws = 0;   // RNG draws made by the last assign (0 = no exact ties)
   unsigned last_flagged = 0;           // rows the MFMA filter sent to the exact kernel
   void ensure(int n, int k, int s);
