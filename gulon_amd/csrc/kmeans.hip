@@ -42,12 +42,24 @@ __global__ void prep_centroids(const float *__restrict__ C, int k, int s, int sm
 // rng.nextBoolean() read as false).  assign[] is written only when some centroid
 // won, exactly like the reference (NaN distances never win).
 // ---------------------------------------------------------------------------
-template <int SMAX>
+// STAGE: the padded centroids and their offsets are copied to LDS first (k * (SMAX + 1) floats <= 64 KiB).  Every
+// lane reads the same centroid, so from global memory these are scalar loads that the loop waits for centroid by
+// centroid (the re-check of 120 K flagged rows: 125 us, a few hundred cycles of load latency per centroid); from LDS
+// they are broadcast reads the compiler can request several centroids ahead.
+template <int SMAX, bool STAGE>
 __global__ __launch_bounds__(256) void assign_exact(const float *__restrict__ X, int n, int ld, int from, int s,
                                                     const float *__restrict__ Cpad, const float *__restrict__ off,
                                                     int k, const int *__restrict__ rows, int nrows,
                                                     int *__restrict__ assign, unsigned *__restrict__ ties,
                                                     unsigned long long *__restrict__ tie_total) {
+  extern __shared__ float exact_lds[];   // STAGE: [k][SMAX] centroids, then [k] offsets
+  if (STAGE) {
+    for (int e = threadIdx.x; e < k * SMAX; e += 256) exact_lds[e] = Cpad[e];
+    for (int e = threadIdx.x; e < k; e += 256) exact_lds[k * SMAX + e] = off[e];
+    __syncthreads();
+  }
+  const float *const cbase = STAGE ? exact_lds : Cpad;
+  const float *const obase = STAGE ? exact_lds + k * SMAX : off;
   int t = blockIdx.x * 256 + threadIdx.x;
   int i = -1;
   if (t < nrows) i = rows ? rows[t] : t;
@@ -63,12 +75,13 @@ __global__ __launch_bounds__(256) void assign_exact(const float *__restrict__ X,
   float mn = FLT_MAX;
   int best = -1;
   unsigned nt = 0;
+#pragma unroll 4
   for (int c = 0; c < k; c++) {
-    const float *cc = Cpad + (size_t)c * SMAX;
+    const float *cc = cbase + (size_t)c * SMAX;
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < SMAX; j++) d += x[j] * cc[j];
-    d = off[c] - 2 * d;
+    d = obase[c] - 2 * d;
     if (d < mn) { mn = d; best = c; }
     else if (d == mn) nt++;
   }
@@ -879,9 +892,20 @@ static void launch_exact(AssignJob &j) {
   KmeansWorkspace &ws = *j.ws;
   const int smax = pick_smax(j.s);
   const int grid = ceil_div(j.nrows, 256);
+  // centroids + offsets in LDS when they fit 64 KiB (k = 256: 17 KiB at s <= 16)
 #define AE(S)                                                                                                      \
-  hipLaunchKernelGGL(assign_exact<S>, dim3(grid), dim3(256), 0, j.st, j.dX, j.n, j.ld, j.from, j.s, ws.cpad.p,     \
-                     ws.off.p, j.k, j.rows, j.nrows, j.d_assign, ws.ties.p, ws.tie_total.p)
+  do {                                                                                                             \
+    const size_t lds_ = sizeof(float) * (size_t)j.k * (S + 1);                                                     \
+    if (lds_ <= 64 * 1024) {                                                                                       \
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assign_exact<S, true>),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                        \
+      hipLaunchKernelGGL((assign_exact<S, true>), dim3(grid), dim3(256), lds_, j.st, j.dX, j.n, j.ld, j.from, j.s, \
+                         ws.cpad.p, ws.off.p, j.k, j.rows, j.nrows, j.d_assign, ws.ties.p, ws.tie_total.p);        \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((assign_exact<S, false>), dim3(grid), dim3(256), 0, j.st, j.dX, j.n, j.ld, j.from, j.s,   \
+                         ws.cpad.p, ws.off.p, j.k, j.rows, j.nrows, j.d_assign, ws.ties.p, ws.tie_total.p);        \
+    }                                                                                                              \
+  } while (0)
   switch (smax) {
     case 4: AE(4); break;
     case 8: AE(8); break;
