@@ -42,7 +42,8 @@ __global__ void prep_centroids(const float *__restrict__ C, int k, int s, int sm
 // rng.nextBoolean() read as false).  assign[] is written only when some centroid
 // won, exactly like the reference (NaN distances never win).
 // ---------------------------------------------------------------------------
-// STAGE: the padded centroids and their offsets are copied to LDS first (k * (SMAX + 1) floats <= 64 KiB).  Every
+// STAGE: the padded centroids and their offsets are copied to LDS first (k * (SMAX + 1) floats <= 64 KiB), pairs of
+// centroids interleaved per dimension.  Every
 // lane reads the same centroid, so from global memory these are scalar loads that the loop waits for centroid by
 // centroid (the re-check of 120 K flagged rows: 125 us, a few hundred cycles of load latency per centroid); from LDS
 // they are broadcast reads the compiler can request several centroids ahead.
@@ -52,14 +53,16 @@ __global__ __launch_bounds__(256) void assign_exact(const float *__restrict__ X,
                                                     int k, const int *__restrict__ rows, int nrows,
                                                     int *__restrict__ assign, unsigned *__restrict__ ties,
                                                     unsigned long long *__restrict__ tie_total) {
-  extern __shared__ float exact_lds[];   // STAGE: [k][SMAX] centroids, then [k] offsets
+  extern __shared__ float exact_lds[];   // STAGE: [ceil(k/2)][SMAX][2] centroid PAIRS (c, c+1 interleaved per dim), then [k] offsets
+  const int kp = (k + 1) / 2;
   if (STAGE) {
-    for (int e = threadIdx.x; e < k * SMAX; e += 256) exact_lds[e] = Cpad[e];
-    for (int e = threadIdx.x; e < k; e += 256) exact_lds[k * SMAX + e] = off[e];
+    for (int e = threadIdx.x; e < kp * SMAX * 2; e += 256) {
+      const int cp = e / (2 * SMAX), r = e - cp * 2 * SMAX, j = r >> 1, c = 2 * cp + (r & 1);
+      exact_lds[e] = c < k ? Cpad[(size_t)c * SMAX + j] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 2 * kp; e += 256) exact_lds[kp * SMAX * 2 + e] = e < k ? off[e] : 0.f;
     __syncthreads();
   }
-  const float *const cbase = STAGE ? exact_lds : Cpad;
-  const float *const obase = STAGE ? exact_lds + k * SMAX : off;
   int t = blockIdx.x * 256 + threadIdx.x;
   int i = -1;
   if (t < nrows) i = rows ? rows[t] : t;
@@ -75,15 +78,40 @@ __global__ __launch_bounds__(256) void assign_exact(const float *__restrict__ X,
   float mn = FLT_MAX;
   int best = -1;
   unsigned nt = 0;
-#pragma unroll 4
-  for (int c = 0; c < k; c++) {
-    const float *cc = cbase + (size_t)c * SMAX;
-    float d = 0.f;
+  if (STAGE) {
+    // two centroids per step on the packed fp32 pipe: each component is the reference's own sequential, unfused chain
+    // (v_pk_mul_f32 / v_pk_add_f32 round every component like their scalar forms); the comparisons stay in centroid
+    // order.  The kernel is bound by its arithmetic (k * s products per row), so this halves it.
+    const f32x2 *pairs = reinterpret_cast<const f32x2 *>(exact_lds);
+    const f32x2 *offs = reinterpret_cast<const f32x2 *>(exact_lds + kp * SMAX * 2);
+#pragma unroll 2
+    for (int cp = 0; cp < kp; cp++) {
+      const f32x2 *cc = pairs + (size_t)cp * SMAX;
+      f32x2 d = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < SMAX; j++) d += x[j] * cc[j];
-    d = obase[c] - 2 * d;
-    if (d < mn) { mn = d; best = c; }
-    else if (d == mn) nt++;
+      for (int j = 0; j < SMAX; j++) {
+        const f32x2 xx = {x[j], x[j]};
+        d = d + xx * cc[j];
+      }
+      const f32x2 two = {2.f, 2.f};
+      d = offs[cp] - two * d;
+      if (d.x < mn) { mn = d.x; best = 2 * cp; }
+      else if (d.x == mn) nt++;
+      if (2 * cp + 1 < k) {
+        if (d.y < mn) { mn = d.y; best = 2 * cp + 1; }
+        else if (d.y == mn) nt++;
+      }
+    }
+  } else {
+    for (int c = 0; c < k; c++) {
+      const float *cc = Cpad + (size_t)c * SMAX;
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < SMAX; j++) d += x[j] * cc[j];
+      d = off[c] - 2 * d;
+      if (d < mn) { mn = d; best = c; }
+      else if (d == mn) nt++;
+    }
   }
   if (i >= 0) {
     if (best >= 0) assign[i] = best;
@@ -895,7 +923,7 @@ static void launch_exact(AssignJob &j) {
   // centroids + offsets in LDS when they fit 64 KiB (k = 256: 17 KiB at s <= 16)
 #define AE(S)                                                                                                      \
   do {                                                                                                             \
-    const size_t lds_ = sizeof(float) * (size_t)j.k * (S + 1);                                                     \
+    const size_t lds_ = sizeof(float) * (size_t)((j.k + 1) / 2) * 2 * (S + 1);                                     \
     if (lds_ <= 64 * 1024) {                                                                                       \
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assign_exact<S, true>),                         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                        \
