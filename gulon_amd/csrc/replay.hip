@@ -459,9 +459,11 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   if (until <= from) return;
   const int rb_begin = from / 64, rb_end = ceil_div(until, 64), rb_total = rb_end - rb_begin;
   // y extent of the scan grids (a block walks the flagged queries y, y + Y, ...): the two short levels have few
-  // segments, so every flagged query gets blocks of its own -- a batch in which all 1024 queries tie spent 3.7 ms
-  // in them with 16; the long level keeps 16 (its x extent fills the chip; blocks without a query cost a launch slot)
-  const int gy_short = std::min(F, 256), gy = std::min(F, 16);
+  // segments, so every flagged query gets blocks of its own once the handle has seen batches with many of them
+  // (rp_hint, below) -- a batch in which all 1024 queries tie spent 3.7 ms in them with 16; the long level keeps 16
+  // (its x extent fills the chip; blocks without a query cost a launch slot)
+  const int gy = std::min(F, 16);
+  const int gy_short = recently_flagged >= 32 ? std::min(F, 256) : gy;
   // level geometry (in 64-row blocks)
   const int l0 = std::min(rb_total, RP_L0_BLOCKS);
   const int l1 = std::min(rb_total - l0, RP_L1_BLOCKS);
@@ -536,13 +538,16 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
 
 // Literal heap over the candidates of `lists` packs (one per row shard, same flagged-query list).
 void replay_apply(const int *packs, int lists, long long stride_words, int F, int C, int K, int *d_oi, float *d_od,
-                  int *d_oc, int *d_of, unsigned long long *dbgp, hipStream_t st) {
+                  int *d_oc, int *d_of, unsigned long long *dbgp, hipStream_t st, bool many_flagged = false) {
   int lds_pool = 64;   // a power of two: the bitonic sort pads the candidates to one
   while (lds_pool < RP_LDS_POOL && lds_pool < (long long)lists * C) lds_pool <<= 1;
   const size_t heap_lds = (size_t)(2 * lds_pool + 2 * RP_KEEP) * sizeof(float);
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rp_heap), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)heap_lds));
-  hipLaunchKernelGGL(rp_heap, dim3(std::min(F, 1024)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
+  // a block per flagged query only when the handle has recently seen many of them: every block wants 80+ KiB of LDS,
+  // which the other batch's filter kernel does not leave free -- 1024 blocks waiting for it took 1.2 ms for the
+  // usual single flagged query (64 blocks: 0.29 ms)
+  hipLaunchKernelGGL(rp_heap, dim3(std::min(F, many_flagged ? 1024 : 64)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
                      K, d_oi, d_od, d_oc, d_of, dbgp);
   HIP_CHECK(hipGetLastError());
   if (dbgp) {
@@ -567,7 +572,8 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
   if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
   for (int skip = 0; skip < B; skip += F) {
     replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st, skip);
-    replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st);
+    replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st,
+                 ix->rp_hint_h && *reinterpret_cast<volatile int *>(ix->rp_hint_h) >= 32);
   }   // (byte codes: F = min(B, 1024) -- one round unless the batch is larger than that)
 }
 
