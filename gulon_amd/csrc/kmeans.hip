@@ -1342,14 +1342,26 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     bool done = false;
     bool shared_stream = false;
     int nrep = 0;
-    ~Prob() {
-      if (st && !shared_stream) (void)hipStreamDestroy(st);
-      if (h_prev) (void)hipHostFree(h_prev);
-      if (h_next) (void)hipHostFree(h_next);
-      if (h_mism) (void)hipHostFree(h_mism);
-    }
+    ~Prob() { if (st && !shared_stream) (void)hipStreamDestroy(st); }
   };
   std::vector<Prob> P(np);
+  // ONE pinned allocation for all problems' host copies (a hipHostMalloc costs milliseconds: three per problem were
+  // 1.5 s of a 32-quantizer training)
+  struct Pinned {
+    void *p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+  } pinned;
+  {
+    size_t words = 0;
+    for (int p = 0; p < np; p++) words += 2 * (size_t)k * sdim[p] + 1;
+    HIP_CHECK(hipHostMalloc(&pinned.p, sizeof(float) * std::max<size_t>(words, 1)));
+    float *w = static_cast<float *>(pinned.p);
+    for (int p = 0; p < np; p++) {
+      P[p].h_prev = w; w += (size_t)k * sdim[p];
+      P[p].h_next = w; w += (size_t)k * sdim[p];
+      P[p].h_mism = reinterpret_cast<unsigned *>(w); w += 1;
+    }
+  }
   auto push_report = [&](int p, const gulon_kmeans_report &r) {
     if (reports && P[p].nrep < max_reports) reports[(size_t)p * max_reports + P[p].nrep] = r;
     P[p].nrep++;
@@ -1396,9 +1408,6 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
     pr.a_prev.alloc(n); pr.a_next.alloc(n);
     pr.mism.alloc(1);
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_prev), sizeof(float) * (size_t)k * s));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_next), sizeof(float) * (size_t)k * s));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pr.h_mism), sizeof(unsigned)));
     // KMeans.init (KMeans.scala:188-196)
     std::vector<int> rows(k);
     JRandom rng((int64_t)seeds[p]);
