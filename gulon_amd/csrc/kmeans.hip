@@ -1436,6 +1436,11 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     HIP_CHECK(hipStreamSynchronize(P[p].st));
   }
   lap("first assign done");
+  if (print) {
+    unsigned long long dr = 0;
+    for (int p = 0; p < np; p++) dr += P[p].ws.last_draws;
+    fprintf(stderr, "[gulon trace]   first assign: tie draws %llu\n", dr);
+  }
 
   for (int i = 0; i <= max_iterations;) {
     std::vector<int> act;

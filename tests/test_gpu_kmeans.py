@@ -245,3 +245,22 @@ def test_fused_update_experiment_is_bit_exact():
     env = dict(os.environ, GULON_UPDATE_FUSED="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n,d,m,k,iters,nbase,part", [(3000, 32, 2, 64, 3, 6, 10), (60000, 48, 3, 80, 2, 8, 10),
+                                                     (60000, 48, 3, 80, 2, 8, 150), (1500, 16, 1, 70, 4, 5, 10)])
+def test_few_exact_ties_take_the_sparse_replay(oracle, g, n, d, m, k, iters, nbase, part):
+    """One row in `part` is a copy of one of a few base rows, so KMeans.init (sampling with replacement) picks some vector
+    twice: two identical centroids, and every row nearest to them is an exact tie that draws from java.util.Random --
+    with few draws per pass (<= 8192; cases 1, 3, 4) the tie replay takes the stream positions from the drawing rows
+    themselves (tie_positions_sparse), across the 25 000-row restarts of parAssign (case 3); case 2 (~20 000 draws per
+    sub-quantizer) keeps the dense prefix sums.  Codebooks must equal the oracle's bit for
+    bit, which they only do if every draw sits at its place in the stream."""
+    rng = np.random.default_rng(n + k)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    base = rng.standard_normal((nbase, d)).astype(np.float32)
+    copies = rng.permutation(n)[:n // part]
+    X[copies] = base[rng.integers(0, nbase, len(copies))]
+    pq = g.ProductQuantizer.apply(g.DeviceMatrix.from_host(X), g.ProductQuantizerConfig(k, m, iters))
+    cents, _, _ = oracle.pq_train(X, m, k, iters)
+    assert np.array_equal(bits(pq.flat_centroids()), bits(cents))
