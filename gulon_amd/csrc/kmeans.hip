@@ -468,6 +468,10 @@ __global__ void sort_scan_top(const UpdDesc *__restrict__ descs, long long ngrou
 // 160-byte runs leave at 3.4 TB/s at best (scripts/micro/store_runs.hip; whole aligned 128-byte lines: 5.7 TB/s) --
 // and a workgroup that lives on has to wait for its own stores before it can trust its look-ahead loads (vmcnt counts
 // both, in order), while a workgroup that ends leaves its stores to drain under the next one's loads.
+// Also measured and dropped: stage D in 16-byte stores (a unit on an even address opens a pair with its successor, run
+// heads and tails leave alone in 8-byte stores of their own): 7.2 ms against 5.9 -- a run then leaves in three
+// instructions instead of one, and what the memory side is short of is requests per line, not bytes per request
+// (WRITE_SIZE = the algorithmic 12.8 GB either way).
 template <int SMAX /* 0: slices go straight to their positions; else staged, s <= SMAX */>
 __global__ __launch_bounds__(256) void sort_place(const UpdDesc *__restrict__ descs, int n, int k, int key_bits,
                                                   int cpx /* > 0: chunks per XCD, 1-D grid */) {
