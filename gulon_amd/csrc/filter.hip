@@ -286,9 +286,10 @@ template <> struct QEntry<16> { using type = uint4; };
 template <> struct QEntry<8> { using type = uint2; };
 template <> struct QEntry<4> { using type = uint32_t; };
 
-template <int QW, int NQG, int VEC, int NADD, int MAIN, int NG1 /* 1: a single code word per row (ng == 1) */>
+template <int QW, int NQG, int VEC, int NADD, int MAIN,
+          int NG1 /* 1: a single code word per row (ng == 1); 2: and `codes` is the conflict-ordered copy, `perm` its row order */>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
-    const uint8_t *__restrict__ codes, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ perm, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
     int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap /* entries per sub-queue */,
     const int *__restrict__ fb_tile, int qt, int B) {
   constexpr int NW = FILTER_THREADS / 64;
@@ -303,9 +304,6 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   // of up front: 3.21, 3.23, 3.36; five 3.96, eight 5.58 -- the L1 path saturates quickly).  It pays only where
   // LDS is the one busy pipe: 16-byte entries, four entries summed per widening, two workgroups per CU (m <= 16);
   // with 4-byte code words, wider indexes (m = 32, 64, 100) or the 7-bit levels it measured 2-50 % slower.
-#ifndef GULON_FILTER_GLB
-#define GULON_FILTER_GLB 3
-#endif
   constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4 && NG1) ? GULON_FILTER_GLB : 0;
   using Word = typename CodeWord<VEC>::type;
   using QE = typename QEntry<QW>::type;
@@ -417,8 +415,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     else
       for (int g = 0; g < ng; g++) word(g, std::false_type{});
 
-    const int row = rb * 64 + lane;
-    const bool valid = row >= row_from && row < row_until;
+    // conflict-ordered copy: which row a lane holds is only looked up (one byte) when a lane has something to report
+    constexpr bool PERM = NG1 == 2;
+    int row = rb * 64 + lane;
+    bool valid = PERM || (row >= row_from && row < row_until);
     uint32_t any = 0;
     uint32_t left[NQG][2 * DW];
 #pragma unroll
@@ -435,6 +435,12 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       int *cnt_l = cnt, *queue_l = queue, *fb_l = const_cast<int *>(fb_tile);
       int slot_l = slot, tile_l = tile;
       asm volatile("" : "+s"(cnt_l), "+s"(queue_l), "+s"(slot_l), "+s"(tile_l), "+s"(fb_l));
+      if (PERM) {
+        const uint8_t *perm_l = perm;
+        asm volatile("" : "+s"(perm_l));
+        row = rb * 64 + perm_l[(size_t)rb * 64 + lane];
+        valid = row >= row_from && row < row_until;
+      }
 #pragma unroll
       for (int s = 0; s < NQG; s++)
 #pragma unroll
@@ -580,15 +586,21 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
   constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
   auto kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, 0> : filter_kernel<QW, NQG, VEC, NADD, 0, 0>;
+  const uint8_t *codes = ix->codes.p, *perm = nullptr;
   if (one_word_form && ix->ng == 1) {
     kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, one_word_form> : filter_kernel<QW, NQG, VEC, NADD, 0, one_word_form>;
+    if (ix->fcodes.p && tuning_of(ix).filter_order > 0) {   // the conflict-ordered copy of the codes (conflict_order.hip)
+      kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, 2 * one_word_form> : filter_kernel<QW, NQG, VEC, NADD, 0, 2 * one_word_form>;
+      codes = ix->fcodes.p;
+      perm = ix->fperm.p;
+    }
     hipFuncAttributes fa;
     HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
     GULON_REQUIRE(fa.sharedSizeBytes == 0, "internal: the single-word filter kernel addresses its tables from LDS offset 0");
   }
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
+  hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, codes, perm, ix->ng, ix->m_pad,
                      ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
                      fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B);
   HIP_CHECK(hipGetLastError());

@@ -625,7 +625,7 @@ ScanTuning::ScanTuning() {
   static const char *keys[] = {"GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE", "GULON_SCAN_PRUNE_FROM", "GULON_SCAN_FILTER",
                                "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
                                "GULON_FILTER_NADD", "GULON_FILTER_SAMPLE", "GULON_FILTER_STAGE0", "GULON_FILTER_BLOCKS",
-                               "GULON_FILTER_SHARED_STAGE1"};
+                               "GULON_FILTER_SHARED_STAGE1", "GULON_FILTER_ORDER"};
   for (const char *k : keys)
     if (const char *e = getenv(k)) set(k, atoi(e));
 }
@@ -645,6 +645,7 @@ bool ScanTuning::set(const char *key, int v) {
   else if (k == "GULON_FILTER_STAGE0") { if (v >= 0) filter_stage0 = v; }
   else if (k == "GULON_FILTER_BLOCKS") { if (v >= 1) filter_blocks = v; }
   else if (k == "GULON_FILTER_SHARED_STAGE1") { if (v >= -1 && v <= 1) filter_shared_stage1 = v; }
+  else if (k == "GULON_FILTER_ORDER") { if (v >= 0 && v <= 8) filter_order = v; }
   else return false;
   return true;
 }
@@ -1001,6 +1002,15 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
                            ix->codes.p, total);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipDeviceSynchronize());
+      // the filter's conflict-ordered copy (one 16-byte code word per row; ranges the filter is never used for
+      // do not need one).  GULON_FILTER_ORDER = rounds of the ordering (0: no copy)
+      const int rounds = tuning().filter_order;
+      if (rounds > 0 && ix->vec == 16 && ix->ng == 1 && (long long)nblk >= tuning().filter_min_rb) {
+        ix->fcodes.alloc(nblk * 1024);
+        ix->fperm.alloc(nblk * 64);
+        launch_conflict_order(ix->codes.p, ix->fcodes.p, ix->fperm.p, (long long)nblk, FILTER_LDS_QUANTIZERS, rounds, 0);
+        HIP_CHECK(hipDeviceSynchronize());
+      }
     }
     HIP_CHECK(hipDeviceSynchronize());
     *out = ix.release();
@@ -1016,6 +1026,8 @@ gulon_index *make_context(gulon_index *parent) {
   c->cents_absmax = parent->cents_absmax;
   c->tune = parent->tune;
   c->codes.borrow(parent->codes);
+  c->fcodes.borrow(parent->fcodes);
+  c->fperm.borrow(parent->fperm);
   c->wcodes.borrow(parent->wcodes);
   c->cents.borrow(parent->cents);
   c->from.borrow(parent->from);

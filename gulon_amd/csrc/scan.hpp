@@ -33,6 +33,9 @@ struct gulon_index {
   int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
   int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
   DevBuf<uint8_t> codes;   // [n/64][ng][64][vec]
+  // the filter's own copy of one-word codes (m <= 16), rows re-dealt inside every 64-row block for the LDS bank
+  // conflicts of its table gathers (conflict_order.hip), and each lane's place in the block's row order
+  DevBuf<uint8_t> fcodes, fperm;   // [n/64][64][16], [n/64][64]
   bool wide = false;       // k > 256: 16-bit codes, tables in HBM (wide.hip)
   DevBuf<uint16_t> wcodes; // wide: [n/64][m][64]
   DevBuf<float> wpartial;  // wide, sliced tables: running sums [queries of the sub-batch][rows]
@@ -143,6 +146,13 @@ inline int rbmap_count(int rb_total, RbMap mp) {
 }
 
 // launch shape knobs (environment overrides / gulon_scan_tuning are for experiments and tests)
+// filter.hip: of the 16 quantizers of a one-word code, the entries of the last GULON_FILTER_GLB are fetched through
+// the vector L1 instead of LDS; conflict_order.hip orders rows for the bank conflicts of the others
+#ifndef GULON_FILTER_GLB
+#define GULON_FILTER_GLB 3
+#endif
+constexpr int FILTER_LDS_QUANTIZERS = 16 - GULON_FILTER_GLB;
+
 struct ScanTuning {
   int threads = 1024;        // workgroup size (16 waves hide the pruning checkpoints' LDS drain)
   int target_blocks = 4096;  // workgroups per launch aimed for
@@ -158,6 +168,7 @@ struct ScanTuning {
   int filter_nadd = 0;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels, 0: by m)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch
   int filter_shared_stage1 = -1;    // bounds shared across shards: run the short first stage? (-1: by sample size)
+  int filter_order = 1;             // conflict-ordered code copy: built at index creation (process-wide value) / used (per handle)
   ScanTuning();
   bool set(const char *key, int v);
 };
@@ -231,4 +242,6 @@ void run_nonfinite_literal(gulon_index *ix, const float *dQ, int B, int K, int f
 // reference's TopKHeap semantics (insertion history in row order) -- replay.hip
 void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, int until, int *d_oi, float *d_od,
                     int *d_oc, int *d_of, hipStream_t st);
+void launch_conflict_order(const uint8_t *src, uint8_t *dst, uint8_t *perm, long long nblk, int nq, int rounds,
+                           hipStream_t st);
 }  // namespace gulon

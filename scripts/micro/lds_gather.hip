@@ -4,6 +4,8 @@
 //   mode 4: lane quads read the four quarters of one random 64-B entry
 //   mode 16: 16 lanes read one random 256-B row (conflict-free reference)
 //   mode 0: random row per lane, column = lane % 16 (distinct bank groups inside each 16-lane group)
+//   modes 102 / 103 / 104: random row per lane, column = lane % 8 / % 6 / % 4: at most 2 / 3 / 4 lanes of a 16-lane
+//     group in one bank group (different rows) -- the cost model "a pass of 16 lanes takes max(2, largest load) cycles"
 // build: hipcc --offload-arch=gfx950 -O3 -o lds_gather lds_gather.hip ; run: ./lds_gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(1024) void gather(const uint4 *__restrict__ codes, 
       const int per_b = 512 / (SHARE == 0 ? 1 : SHARE);   // distinct entries available per b (LDS capacity)
       // SHARE == 0: every lane its own random 256-B row, but the 16 lanes of a group in 16 different
       // 16-B columns (conflict-free if the bank is address bits [7:4] only)
-      const int idx = SHARE == 0 ? b * 512 + (c % 32) * 16 + (lane & 15) : b * 512 + (c % per_b) * SHARE + (lane % SHARE);
+      const int idx = SHARE > 100 ? b * 512 + (c % 32) * 16 + (lane % (SHARE == 102 ? 8 : SHARE == 103 ? 6 : 4)) : SHARE == 0 ? b * 512 + (c % 32) * 16 + (lane & 15) : b * 512 + (c % per_b) * SHARE + (lane % SHARE);
       const uint4 x = lds[idx];
       acc.x += x.x; acc.y ^= x.y; acc.z += x.z; acc.w ^= x.w;
     }
@@ -68,6 +70,9 @@ int main() {
   };
   run(gather<1>, "own16B");
   run(gather<0>, "owncol");
+  run(gather<102>, "load2");
+  run(gather<103>, "load3");
+  run(gather<104>, "load4");
   run(gather<2>, "pair32B");
   run(gather<4>, "quad64B");
   run(gather<16>, "row256B");
