@@ -1,0 +1,59 @@
+"""Cost model of one ds_read_b128 wave-instruction on gfx950, fitted to scripts/micro/lds_pattern.hip.
+
+  build/expt/lds_pattern      > patterns.txt     (262 address patterns: name, cycles, 64 entry indices)
+  build/expt/lds_pattern swap > swaps.txt        (linear addresses with two lanes exchanged)
+  python3 scripts/micro/lds_pattern_fit.py patterns.txt swaps.txt
+
+1. swaps.txt gives the lane groups: exchanging the addresses of lanes i and j of a conflict-free pattern costs
+   nothing iff both are served together.  Result: {0-3, 12-15, 20-23, 24-27}, {4-7, 8-11, 16-19, 28-31}, and both + 32.
+2. patterns.txt checks   cycles = sum over the four groups of (most DISTINCT addresses in one 16-byte bank column,
+   column = entry index mod 16) + 0.5   -- rms error 0.27 cycles over all patterns, correlation 0.998 on random ones
+   (mean 11.7 + 0.5 predicted, 12.1 measured); the only misfit is the floor of 5.4 cycles where the model says 4.
+conflict_order.hip orders the rows of the filter's code copy by this model.
+"""
+import sys
+import numpy as np
+
+
+def groups_from_swaps(path):
+    t = np.full((64, 64), np.nan)
+    for line in open(path):
+        f = line.split()
+        _, i, j = f[0].split("_")
+        t[int(i), int(j)] = t[int(j), int(i)] = float(f[1])
+    lo = np.nanmin(t)
+    groups, seen = [], set()
+    for i in range(64):
+        if i in seen:
+            continue
+        same = {i} | {j for j in range(64) if not np.isnan(t[i, j]) and t[i, j] < lo + 0.7}
+        # lanes with the same column as i (never exchanged) belong to other groups
+        groups.append(sorted(same))
+        seen |= same
+    return groups
+
+
+def fit(path, groups):
+    rows = [line.split() for line in open(path)]
+    names = [r[0] for r in rows]
+    t = np.array([float(r[1]) for r in rows])
+    pats = np.array([[int(x) for x in r[2:]] for r in rows])
+
+    def fullest(idx):
+        per = {}
+        for a in set(idx):
+            per[a % 16] = per.get(a % 16, 0) + 1
+        return max(per.values())
+    pred = np.array([sum(fullest([p[lane] for lane in g]) for g in groups) for p in pats], float)
+    a, b = np.polyfit(pred, t, 1)
+    rnd = np.array([n == "rand256" for n in names])
+    print(f"all {len(t)} patterns: cycles = {a:.3f} * model + {b:.2f}, rms error {(t - a * pred - b).std():.3f}")
+    print(f"random 256-entry tables: correlation {np.corrcoef(pred[rnd], t[rnd])[0, 1]:.3f}, "
+          f"model mean {pred[rnd].mean():.2f}, measured mean {t[rnd].mean():.2f}")
+
+
+if __name__ == "__main__":
+    g = groups_from_swaps(sys.argv[2])
+    for grp in g:
+        print("group:", grp)
+    fit(sys.argv[1], g)
