@@ -147,3 +147,21 @@ void launch_conflict_order(const uint8_t *src, uint8_t *dst, uint8_t *perm, long
 }
 
 }  // namespace gulon
+
+using namespace gulon;
+
+GULON_API int32_t gulon_selftest_conflict_order(const uint8_t *codes, int64_t n_blocks, int32_t rounds, uint8_t *codes_out,
+                                                uint8_t *place_out) {
+  return guarded([&] {
+    GULON_REQUIRE(codes != nullptr && codes_out != nullptr && place_out != nullptr && n_blocks >= 0 && rounds >= 0 && rounds <= 8,
+                  "bad arguments");
+    if (n_blocks == 0) return;
+    DevBuf<uint8_t> src, dst((size_t)n_blocks * 1024), place((size_t)n_blocks * 64);
+    src.upload(codes, (size_t)n_blocks * 1024);
+    launch_conflict_order(src.p, dst.p, place.p, n_blocks, FILTER_LDS_QUANTIZERS, rounds, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(codes_out, dst.p, (size_t)n_blocks * 1024, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(place_out, place.p, (size_t)n_blocks * 64, hipMemcpyDeviceToHost));
+  });
+}
+

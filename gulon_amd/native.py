@@ -83,6 +83,7 @@ SIGNATURES = {
     "gulon_kmeans_train": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32,
                                   C.POINTER(_i32)]),
     "gulon_selftest_mean_division": (_i32, [_i32, _i32, C.c_uint64, C.POINTER(C.c_int64)]),
+    "gulon_selftest_conflict_order": (_i32, [C.c_void_p, C.c_int64, _i32, C.c_void_p, C.c_void_p]),
     "gulon_selftest_assign_band": (_i32, [_i32, C.c_uint64, C.c_float, C.POINTER(C.c_double)]),
     "gulon_kmeans_trace": (_i32, [_i32]),
     "gulon_kmeans_trace_read": (_i32, [C.POINTER(KMeansTraceTotals)]),

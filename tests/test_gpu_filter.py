@@ -12,7 +12,7 @@ from test_gpu_query import _check, _make
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_MIN_RB": 512, "GULON_FILTER_PERIOD": 128,
+DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_ORDER": 1, "GULON_FILTER_MIN_RB": 512, "GULON_FILTER_PERIOD": 128,
             "GULON_FILTER_STAGE0": 0, "GULON_FILTER_STAGE1": 6, "GULON_FILTER_CAP": 32768,
             "GULON_FILTER_NADD": 0, "GULON_FILTER_SAMPLE": 65536}
 
@@ -322,3 +322,63 @@ def test_two_batches_in_flight_on_two_streams():
     p.join(300)
     assert p.exitcode == 0
     assert out.get(timeout=5) == 1
+
+
+# ---- the conflict-ordered copy of the codes (conflict_order.hip) ---------------------------------------------------
+LDS_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+LDS_GROUPS += [[lane + 32 for lane in grp] for grp in LDS_GROUPS]
+
+
+def _gather_cycles(block, nq=13):
+    """The measured cost model of the filter's table gathers (scripts/micro/lds_pattern_fit.py): per quantizer, the sum
+    over the four lane groups of the most distinct codes in one bank column (code mod 16)."""
+    total = 0
+    for q in range(nq):
+        for grp in LDS_GROUPS:
+            codes = set(int(c) for c in block[grp, q])
+            total += np.bincount([c % 16 for c in codes], minlength=16).max()
+    return total
+
+
+def test_conflict_order_is_a_permutation_and_lowers_the_model_cost(g):
+    from gulon_amd import native as N
+    nblk = 600
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, 256, (nblk, 64, 16), dtype=np.uint8)
+    codes[5] = 7                                   # a block whose rows are all alike
+    codes[6, :, :] = codes[6, :1, :]
+    codes[7, :, 3] = np.arange(64) * 16 % 256      # one quantizer whose codes all share a bank column
+    out, place = np.empty_like(codes), np.empty((nblk, 64), np.uint8)
+    for rounds in (0, 1, 2):
+        N.check(N.lib().gulon_selftest_conflict_order(codes.ctypes.data, nblk, rounds, out.ctypes.data, place.ctypes.data))
+        assert np.array_equal(np.sort(place, axis=1), np.tile(np.arange(64, dtype=np.uint8), (nblk, 1)))
+        assert np.array_equal(out, np.take_along_axis(codes, place[:, :, None].astype(np.int64), axis=1))
+        if rounds == 0:
+            assert np.array_equal(place, np.tile(np.arange(64, dtype=np.uint8), (nblk, 1)))
+            continue
+        before = sum(_gather_cycles(codes[b]) for b in range(100, 300))
+        after = sum(_gather_cycles(out[b]) for b in range(100, 300))
+        assert after < 0.83 * before, (before, after)       # simulated: 12.3 -> 9.6 cycles per gather after one round
+        for b in (5, 6, 7):
+            assert _gather_cycles(out[b]) <= _gather_cycles(codes[b])
+
+
+@pytest.mark.parametrize("n,frm,until", [(70001, 0, None), (70001, 12345, 60001), (40000, 63, 39937), (33000, 1000, 1100)])
+def test_conflict_ordered_copy_equals_plain_codes(oracle, g, tune, n, frm, until):
+    """The filter reads its own re-dealt copy of the codes and maps surviving lanes back to rows; ranges that cut
+    blocks, a ragged last block: the same answers as with the plain copy (per-handle switch) and as the oracle."""
+    from gulon_amd import native as N
+    d, m, k, B, K = 128, 16, 256, 40, 10
+    cents, idx, pq, enc = _make(oracle, g, n, d, m, k, seed=n)
+    Q = np.random.default_rng(5).standard_normal((B, d)).astype(np.float32)
+    ix = g.PQIndex(pq, enc)
+    ordered = ix.batch_query(K, Q, frm, until)
+    N.check(N.lib().gulon_index_tuning(ix._h, b"GULON_FILTER_ORDER", 0))
+    plain = ix.batch_query(K, Q, frm, until)
+    for x, y in zip(ordered, plain):
+        assert x.rows.tolist() == y.rows.tolist()
+        assert np.array_equal(bits(x.distances), bits(y.distances))
+        assert x.flags == y.flags
+    oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
+    _check(oracle, ordered, oi, od, oc)
+    ix.close()
