@@ -26,7 +26,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_B
   n=pmc_filter_$(echo $grp | tr ' ' '_' | cut -c1-40)
   pmc $n "$grp" python3 $root/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-recall --no-extras
 done
-(cd "$root" && python3 scripts/pmc_summary.py "filter_kernel<16, 1, 16, 4, 1, 1>" $out/pmc_filter_* > "$out/filter_kernel_pmc.csv")
+(cd "$root" && python3 scripts/pmc_summary.py "filter_kernel<16, 1, 16, 4, 1, 2>" $out/pmc_filter_* > "$out/filter_kernel_pmc.csv")
 cat "$out/filter_kernel_pmc.csv"
 # 2. the exact scan (filter off)
 GULON_SCAN_FILTER=0 stats bench_exact_scan python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall --no-extras
