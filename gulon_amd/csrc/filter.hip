@@ -681,15 +681,16 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 __global__ void rp_filter_bounds(const int *__restrict__ count, int F, int min_flagged, int K,
                                  const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
                                  float *__restrict__ tau, int *__restrict__ fb, float *__restrict__ fin_v,
-                                 int *__restrict__ fin_i, int n_pad) {
+                                 int *__restrict__ fin_i, int n_pad, const int *__restrict__ done /* [F] or null */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_pad) return;
   const int nf = min(*count, F);
   float t = INFINITY;
-  if (f < nf && nf >= min_flagged && prefix_c[f] >= K) t = prefix_v[(size_t)f * K + K - 1];
+  const bool served = done && f < F && done[f] != 0;   // replay.hip, rp_shortcut: nothing left to find for this query
+  if (!served && f < nf && nf >= min_flagged && prefix_c[f] >= K) t = prefix_v[(size_t)f * K + K - 1];
   const bool live = t < INFINITY;            // (false for NaN too)
   tau[f] = live ? t : INFINITY;
-  fb[f] = live ? 0 : 1;
+  fb[f] = live ? 0 : served ? 2 : 1;         // 1: left to the segment scan
   fin_v[f] = INFINITY;                       // a one-entry "running list" that never tightens the bound
   fin_i[f] = INT_MAX;
 }
@@ -979,7 +980,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 
 bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi, int from, int until,
                             const float *tables, const float *mins, const float *prefix_v, const int *prefix_c,
-                            const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st) {
+                            const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st,
+                            const int *done) {
   const ScanTuning &t = tuning_of(ix);
   const int e_count = rb_hi - rb_lo;
   // (the same conditions as filter_eligible; the byte-code kernels only)
@@ -999,7 +1001,7 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   ix->sv_cnt.ensure((size_t)Fq * NSLOT);
   ix->sv_queue.ensure((size_t)Fq * NSLOT * cap);
   hipLaunchKernelGGL(rp_filter_bounds, dim3(ceil_div(Fq, 256)), dim3(256), 0, st, count, F, min_flagged, K, prefix_v, prefix_c,
-                     ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p, Fq);
+                     ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p, Fq, done);
   HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Fq * NSLOT, st));
   // tables of the flagged queries are [f][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms; queries
   // beyond F (the padding of the last 16-query group) read no table

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
   const int nf = min(*count, maxf);
   // the grid has a fixed, small y extent; each block walks the flagged queries f = y, y+Y, ...
   for (int f = blockIdx.y; f < nf; f += gridDim.y) {
-    if (only && only[f] == 0) continue;     // (uniform) this query's rows came through the quantized filter
+    if (only && only[f] != 1) continue;     // (uniform) 0: this query's rows came through the quantized filter; 2: rp_shortcut
     __syncthreads();
     {
       const float *src = tables + (size_t)f * m_pad * 256;
@@ -442,8 +442,50 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
 }
 
 // Candidates of the flagged queries over rows [from, until) of this index (cold start at `from`).
+// The long level without a scan.  If the K-th smallest distance of the earlier rows (the bound level 2 starts from) IS
+// the K-th smallest distance of the whole range -- what the main pass returned -- then every later row that can
+// still insert (distance strictly below the bound; TopKHeap.update rejects an equal one) is one of the fewer than K
+// rows below the final K-th distance, and all of those are in the main pass's list.  That is the all-ties case of the
+// reference-shaped data (thousands of rows share the query's code: the first K of them fill the heap within the
+// first levels); the query's level-2 candidates are then read off its result.  done[f] = 2 / scanme[f] = 0 for
+// such a query (1 where the scan still has to walk).
+__global__ void rp_shortcut(const int *__restrict__ count, const int *__restrict__ list, int F, int K,
+                            const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
+                            const float *__restrict__ fin_d, const int *__restrict__ fin_i, const int *__restrict__ fin_c,
+                            int first_row /* global id of level 2's first row */, int pool, float *__restrict__ evv,
+                            int *__restrict__ evi, int *__restrict__ evcnt, int *__restrict__ done,
+                            int *__restrict__ scanme) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int nf = min(*count, F);
+  bool hit = false;
+  if (f < nf && prefix_c[f] >= K) {
+    const int q = list[f];
+    const float bound = prefix_v[(size_t)f * K + K - 1];
+    if (q >= 0 && fin_c[q] == K && bound < INFINITY &&
+        __float_as_uint(bound) == __float_as_uint(fin_d[(size_t)q * K + K - 1])) {
+      hit = true;
+      int n = 0;
+      for (int i = 0; i < K; i++)
+        if (fin_d[(size_t)q * K + i] < bound && fin_i[(size_t)q * K + i] >= first_row) n++;
+      int pos = n > 0 ? atomicAdd(&evcnt[f], n) : 0;
+      for (int i = 0; i < K; i++) {
+        const float d = fin_d[(size_t)q * K + i];
+        const int r = fin_i[(size_t)q * K + i];
+        if (d < bound && r >= first_row) {
+          if (pos < pool) { evv[(size_t)f * pool + pos] = d; evi[(size_t)f * pool + pos] = r; }
+          pos++;
+        }
+      }
+    }
+  }
+  done[f] = hit ? 2 : 0;
+  scanme[f] = hit ? 0 : 1;
+}
+
 void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, int until, const int *d_flags, int F,
-                    int C, int *pack, hipStream_t st, int skip = 0) {
+                    int C, int *pack, hipStream_t st, int skip = 0, const float *fin_d = nullptr,
+                    const int *fin_i = nullptr, const int *fin_c = nullptr /* the main pass's [B][K] result, if at hand */) {
   const Pack pk{pack, F, C};
   // how many queries recent batches of this handle had flagged: read without synchronisation (the word lags by the
   // batches in flight), it only decides whether the long level is worth the quantized filter's launches -- a batch
@@ -519,9 +561,19 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
       // the literal heap applies TopKHeap's own test, in row order); batches with enough flagged queries take that
       // road, and the segment scan below only walks the queries left to it (`only`).
       int *only = nullptr;
+      const int *done = nullptr;
+      if (fin_d && !ix->wide) {
+        ix->rp_done.ensure((size_t)2 * F);
+        hipLaunchKernelGGL(rp_shortcut, dim3(ceil_div(F, 256)), dim3(256), 0, st, pk.count(), pk.list(), F, K, ix->rp_prefix.p,
+                           ix->rp_precnt.p, fin_d, fin_i, fin_c, (rb_begin + l0 + l1) * 64 + ix->row_base, C, pk.evv(), pk.evi(),
+                           pk.evcnt(), ix->rp_done.p, ix->rp_done.p + F);
+        HIP_CHECK(hipGetLastError());
+        done = ix->rp_done.p;
+        only = ix->rp_done.p + F;
+      }
       if (recently_flagged >= 32)
         replay_level2_filtered(ix, F, K, rb_begin + l0 + l1, rb_end, from, until, ix->rp_tables.p, ix->rp_mins.p,
-                             ix->rp_prefix.p, ix->rp_precnt.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only, st);
+                             ix->rp_prefix.p, ix->rp_precnt.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only, st, done);
       scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr, gy, only);
     }
   }
@@ -532,6 +584,13 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
     fprintf(stderr, "[replay] %d flagged queries; levels %d + %d x %d + %d x %d blocks; candidates:", h[0], l0, segs1,
             RP_L1_SEG, segs2, per2);
     for (int i = 0; i < h[0] && i < 16; i++) fprintf(stderr, " %d", h[4 + F + i]);
+    if (fin_d && !ix->wide && segs2 > 0) {
+      std::vector<int> dn((size_t)F);
+      HIP_CHECK(hipMemcpy(dn.data(), ix->rp_done.p, sizeof(int) * (size_t)F, hipMemcpyDeviceToHost));
+      int hits = 0;
+      for (int i = 0; i < h[0]; i++) hits += dn[i] != 0;
+      fprintf(stderr, "; long level read off the result for %d of them", hits);
+    }
     fprintf(stderr, "\n");
   }
 }
@@ -571,7 +630,7 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
   unsigned long long *dbgp = nullptr;
   if (getenv("GULON_REPLAY_STATS")) { ix->dbg.ensure(8); dbgp = ix->dbg.p; }
   for (int skip = 0; skip < B; skip += F) {
-    replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st, skip);
+    replay_collect(ix, dQ, B, K, from, until, d_of, F, C, ix->rp_pack.p, st, skip, d_od, d_oi, d_oc);
     replay_apply(ix->rp_pack.p, 1, 0, F, C, K, d_oi, d_od, d_oc, d_of, dbgp, st,
                  ix->rp_hint_h && *reinterpret_cast<volatile int *>(ix->rp_hint_h) >= 32);
   }   // (byte codes: F = min(B, 1024) -- one round unless the batch is larger than that)

@@ -149,11 +149,16 @@ def test_exact_heap_replay_many_flagged_long_range(oracle, g, n, d, m, k, K, B, 
     base = rng.integers(0, k, (m, nbase)).astype(np.int32)
     copies = rng.permutation(n)[:n // 2]
     idx[:, copies] = base[:, rng.integers(0, nbase, n // 2)]
+    # ... and a few rows with ONE far copy each: queries that tie without the bound of the early rows being final
+    # (their long level is scanned; the others' is read off the main pass's result, rp_shortcut)
+    lone = np.setdiff1d(np.arange(2000, 4000), copies)[:8]
+    far = np.setdiff1d(np.arange(n - 3000, n - 1000), copies)[:8]
+    idx[:, far] = idx[:, lone]
     pq = g.ProductQuantizer.from_flat(k, d, m, cents)
     coder = pq.coder_factory(n)
     enc = g.EncodedMatrix(coder, [coder.build_code(idx[j]) for j in range(m)])
     ix = g.PQIndex(pq, enc)
-    Q = np.stack([ix.decode(int(r)) for r in copies[:B]]).astype(np.float32)
+    Q = np.stack([ix.decode(int(r)) for r in list(copies[:B - 8]) + list(lone)]).astype(np.float32)
     oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K, frm, n if until is None else until)
     # twice: the handle takes the filtered road once it has SEEN a batch with many flagged queries (a host-mapped
     # hint); the first batch goes through the segment scans, the second through the filter -- same answers
