@@ -353,7 +353,10 @@ int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tiles, int32_t
 /* Launch-shape / algorithm knobs of the scan, process-wide (tests and tuning experiments):
  * key = the name of the corresponding environment variable, e.g. "GULON_SCAN_FILTER" (0/1),
  * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
- * "GULON_FILTER_NADD", "GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE".  Results never depend on them. */
+ * "GULON_FILTER_NADD", "GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE".  Results never depend on them.
+ * "GULON_FILTER_ORDER" (default 1): an index of one-word codes (m <= 16) created while it is non-zero keeps a second,
+ * conflict-ordered copy of its codes for the filter kernel (+ 17 bytes per row; the value = rounds of the ordering);
+ * per handle (gulon_index_tuning) 0 makes the filter read the plain copy again. */
 int32_t gulon_scan_tuning(const char *key, int32_t value);
 /* The same knobs for ONE handle (and the contexts created from it afterwards): two indexes of a process can be
  * tuned independently; a handle without settings of its own follows the process-wide ones. */
