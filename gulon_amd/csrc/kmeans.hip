@@ -1423,12 +1423,14 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(pr.a_prev.p, 0, sizeof(int) * (size_t)n, pr.st));
     pr.use_mfma = mfma_assign_supported(s, k);
-    if (pr.use_mfma) pack_slice(dX, n, ld, from[p], s, k, pr.packed, pr.st);
     pr.xs.alloc((size_t)n * s + 2);   // (+2: update_fused reads rows as pairs of floats)
     GULON_UNSUPPORTED((long long)n * s >= (1ll << 32), "slice of %lld elements: a dispatch carries fewer than 2^32 work-items",
                       (long long)n * s);
     hipLaunchKernelGGL(copy_slice, dim3(ceil_div((long long)n * s, 256)), dim3(256), 0, pr.st, dX, ld, from[p], s,
                        (long long)n * s, pr.xs.p);
+    // the matrix-core operands from the COMPACT copy: the strided slices of the row-major data cost a partial line per
+    // row and pass (pack_slice_split 1.0 ms per sub-quantizer at BASELINE config 3 from the rows, 0.3 from the copy)
+    if (pr.use_mfma) pack_slice(pr.xs.p, n, s, 0, s, k, pr.packed, pr.st);
     make_job(p, pr.c_prev.p, pr.a_prev.p);
     assign_stage1(pr.job);
     push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
