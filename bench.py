@@ -245,12 +245,13 @@ def main():
     nloc = hi - lo
     coder = pq.coder_factory(nloc)
     # one engine (= device index + scratch) and one stream per batch in flight
-    # batches in flight: 2 on one GPU (the second one fills the gaps of the first one's short kernels); 4 when
+    # batches in flight: 3 on one GPU (the others fill the gaps of one batch's short kernels: 2.477 / 2.443 / 2.432 ms
+    # per step for 2 / 3 / 4 at 10 M rows -- the main-stage kernels run back to back from two on); 4 when
     # the shards exchange bounds, lists and replay candidates -- a batch waiting for its all-gathers (whose
     # kernels queue for compute units behind a running filter kernel like every other launch) must not leave
     # the GPU idle (1.25 M-row shard, one-rank RCCL rehearsal: 0.602 / 0.566 / 0.561 ms for 2 / 3 / 4)
     collective = world > 1 or rehearse
-    nfl = args.inflight if args.inflight > 0 else (4 if collective else 2)
+    nfl = args.inflight if args.inflight > 0 else (4 if collective else 3)
     # ONE copy of the shard's codes in HBM; every further batch in flight is a query context over it
     # (gulon_index_context_create: its own scratch, the same codes and codebooks)
     engines = [HipEngine(pq, shard, lo, dev)]
