@@ -164,7 +164,8 @@ struct ScanTuning {
   int filter_period = 128;   // row blocks per sampling period
   int filter_sample = 65536; // most sample rows whose exact distances give the initial bounds
   int filter_stage0 = 0;     // blocks per period scanned by an extra first filter stage (0: none)
-  int filter_stage1 = 6;     // blocks per period scanned by the second filter stage
+  int filter_stage1 = 10;    // blocks per period scanned by the second filter stage (6 until round 2: 2.44 -> 2.38 ms per
+                             // batch at 10 M rows, 0.497 -> 0.469 at 1.25 M; flat from 10 to 20)
   int filter_cap = 32768;    // survivor queue entries per query and stage
   int filter_nadd = 0;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels, 0: by m)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch

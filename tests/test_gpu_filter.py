@@ -13,7 +13,7 @@ from test_gpu_query import _check, _make
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"GULON_SCAN_FILTER": 1, "GULON_FILTER_ORDER": 1, "GULON_FILTER_MIN_RB": 512, "GULON_FILTER_PERIOD": 128,
-            "GULON_FILTER_STAGE0": 0, "GULON_FILTER_STAGE1": 6, "GULON_FILTER_CAP": 32768,
+            "GULON_FILTER_STAGE0": 0, "GULON_FILTER_STAGE1": 10, "GULON_FILTER_CAP": 32768,
             "GULON_FILTER_NADD": 0, "GULON_FILTER_SAMPLE": 65536}
 
 

@@ -29,7 +29,7 @@ def tune(g):
         for k, v in kw.items():
             N.check(N.lib().gulon_scan_tuning(k.encode(), int(v)))
     yield set_
-    set_(GULON_FILTER_MIN_RB=512, GULON_FILTER_PERIOD=128, GULON_FILTER_STAGE0=0, GULON_FILTER_STAGE1=6,
+    set_(GULON_FILTER_MIN_RB=512, GULON_FILTER_PERIOD=128, GULON_FILTER_STAGE0=0, GULON_FILTER_STAGE1=10,
          GULON_FILTER_SAMPLE=65536, GULON_FILTER_SHARED_STAGE1=-1)
 
 
