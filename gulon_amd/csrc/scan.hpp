@@ -39,6 +39,7 @@ struct gulon_index {
   bool wide = false;       // k > 256: 16-bit codes, tables in HBM (wide.hip)
   DevBuf<uint16_t> wcodes; // wide: [n/64][m][64]
   DevBuf<float> wpartial;  // wide, sliced tables: running sums [queries of the sub-batch][rows]
+  DevBuf<uint32_t> wpark;  // wide filter, sliced 8-bit tables: byte sums [query group][row block][64 lanes] (wide_filter.hip)
   DevBuf<float> cents;     // k*d
   DevBuf<int> from, sdim;  // m
   // scratch, grown on demand under `mu`

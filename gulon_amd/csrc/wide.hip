@@ -173,14 +173,38 @@ void launch_build_tables_wide(const float *cents, const int *from, const int *sd
 // its fallback; `enable` selects the queries).  The tables are in ix->tables.
 void launch_scan_wide_range(gulon_index *ix, int B, int K, int from, int until, int rb_begin, int rb_total,
                             int rb_per_chunk, int nchunks, const int *enable, hipStream_t st) {
-  const size_t lds_bytes = (size_t)ix->m * ix->k * sizeof(float);
-  auto kern = scan_wide<true, true, true>;
-  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(B, nchunks), dim3(WIDE_THREADS), lds_bytes, st, ix->wcodes.p, ix->m, ix->k, ix->tables.p,
-                     from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, K + 1, ix->part_v.p,
-                     ix->part_i.p, 0, ix->m, (float *)nullptr, enable);
-  HIP_CHECK(hipGetLastError());
+  const int m = ix->m, k = ix->k;
+  const size_t table_bytes = (size_t)m * k * sizeof(float);
+  auto go = [&](auto kern, size_t lds_bytes, int j0, int j1, float *partial) {
+    if (lds_bytes)
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(B, nchunks), dim3(WIDE_THREADS), lds_bytes, st, ix->wcodes.p, m, k, ix->tables.p,
+                       from, until, ix->row_base, rb_begin, rb_total, rb_per_chunk, nchunks, K + 1, ix->part_v.p,
+                       ix->part_i.p, j0, j1, partial, enable);
+    HIP_CHECK(hipGetLastError());
+  };
+  if (table_bytes <= WIDE_LDS_TABLE) {
+    go(scan_wide<true, true, true>, table_bytes, 0, m, nullptr);
+    return;
+  }
+  // a table beyond LDS (wide_filter.hip's sliced form, k >= 4096 at m = 16): slices of as many quantizers as fit, the
+  // running sums of every (query, row) parked in between -- while that buffer stays small (the filter's sample scan);
+  // else gathered through L2 (its fallback over the whole range: only the queries `enable` selects do any work)
+  const int jp = (int)(WIDE_LDS_TABLE / ((size_t)k * sizeof(float)));
+  const size_t rows_pad = (size_t)rb_total * 64;
+  if (jp >= 1 && (size_t)B * rows_pad * sizeof(float) <= (256ull << 20)) {
+    ix->wpartial.ensure((size_t)B * rows_pad);
+    for (int j0 = 0; j0 < m; j0 += jp) {
+      const int j1 = std::min(m, j0 + jp);
+      const size_t lds_bytes = (size_t)(j1 - j0) * k * sizeof(float);
+      if (j0 == 0) go(scan_wide<true, true, false>, lds_bytes, j0, j1, ix->wpartial.p);
+      else if (j1 == m) go(scan_wide<true, false, true>, lds_bytes, j0, j1, ix->wpartial.p);
+      else go(scan_wide<true, false, false>, lds_bytes, j0, j1, ix->wpartial.p);
+    }
+    return;
+  }
+  go(scan_wide<false, true, true>, 0, 0, m, nullptr);
 }
 
 // Table build + scan + merge of one batch over rows [from, until) of a wide index (run_query's contract).

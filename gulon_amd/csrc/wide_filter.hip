@@ -15,6 +15,10 @@
 //      into the running lists under the (distance, row id) order of the exact scan;
 //   5. a query with an unusable bound (fewer than K+1 sample rows, NaN / inf) or an overflowing queue is redone
 //      by scan_wide over the whole range (decided on the device, per query).
+// Larger code books (k = 4096 ... 32 768 at m = 16, four queries per entry): the group's 8-bit table no longer fits
+// LDS as a whole, so wf_filter walks it in SLICES of as many quantizers as fit (8 at k = 4096), one launch per slice;
+// between the launches the byte sums of every (query, row) are parked in HBM -- one byte each, saturated at 255 (a sum
+// above QMAX - 1 is dead and stays dead), one dword per row and four-query group -- and only the last slice tests.
 #include <climits>
 #include <type_traits>
 
@@ -130,12 +134,16 @@ template <> struct WfEntry<4> { using type = uint32_t; };
 // lane = row; workgroup = QW queries x a chunk of row blocks of [rb_begin, rb_begin + rb_count).
 // MQ = ceil(m / 4) groups of four quantizers, a compile-time bound (0: any m, no look-ahead): the codes of the NEXT
 // row block are requested before the current one's look-ups, so that their latency passes under the LDS gathers.
-template <int QW, int MQ>
+// SLICED (QW = 4, MQ = 0): quantizers [j0, j1) of the table only; park[(tile * rb_count + e) * 64 + lane] holds the
+// byte sums of the earlier slices (j0 > 0) and receives this one's (j1 < m).
+template <int QW, int MQ, bool SLICED = false>
 __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restrict__ codes, int m, int k,
                                                         const uint8_t *__restrict__ qtab, size_t tstride, int row_from, int row_until,
                                                         int rb_begin, int rb_count, int rb_per_chunk,
                                                         int *__restrict__ cnt, int *__restrict__ queue, int cap,
-                                                        int *__restrict__ fb, int B) {
+                                                        int *__restrict__ fb, int B, int j0 = 0, int j1 = 0,
+                                                        uint32_t *__restrict__ park = nullptr) {
+  static_assert(!SLICED || (QW == 4 && MQ > 0), "the sliced form: four queries per entry, at most 4 MQ quantizers per slice");
   constexpr int DW = QW / 4;
   constexpr uint32_t QMAXP = (uint32_t)WF_QMAX * 0x00010001u;   // survive <=> sum <= QMAX - 1
   using QE = typename WfEntry<QW>::type;
@@ -149,21 +157,30 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
     for (int s = 0; s < QW; s++) live = live || (tile * QW + s < B && fb[tile * QW + s] == 0);
     if (!live) return;
   }
-  {   // the group's tables: tstride bytes (m * k * QW rounded up to 16)
+  if (SLICED) {   // quantizers [j0, j1) of the group's tables: (j1 - j0) * k entries of four bytes
+    const int n4 = (j1 - j0) * k;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(qtab + (size_t)tile * tstride) + (size_t)j0 * k;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(wf_lds_raw);
+    for (int e = tid; e < n4; e += WF_THREADS) dst[e] = src[e];
+  } else {   // the group's tables: tstride bytes (m * k * QW rounded up to 16)
     const int n16 = (int)(tstride / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(qtab + (size_t)tile * tstride);
     for (int e = tid; e < n16; e += WF_THREADS) wf_lds_raw[e] = src[e];
   }
   __syncthreads();
+  const int jlo = SLICED ? j0 : 0, jhi = SLICED ? j1 : m;
   const int slot = (chunk * WF_NW + wave) & (WF_NSLOT - 1);
   const int e0 = chunk * rb_per_chunk, e1 = min(rb_count, e0 + rb_per_chunk);
   constexpr int MC = MQ > 0 ? 4 * MQ : 1;
-  unsigned short cn[MC];                 // MQ > 0: codes of the row block about to be processed
+  unsigned short cn[MC];                 // MQ > 0: codes of the row block about to be processed (SLICED: of its slice)
+  uint32_t pn = 0;                       // SLICED, j0 > 0: its parked byte sums
   auto fetch = [&](int e) {
     if (MQ == 0) return;
-    const uint16_t *p = codes + (size_t)(rb_begin + min(e, rb_count - 1)) * m * 64 + lane;   // (clamped: always valid)
+    const int ec = min(e, rb_count - 1);                                                     // (clamped: always valid)
+    const uint16_t *p = codes + (size_t)(rb_begin + ec) * m * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < MC; j++) cn[j] = j < m ? p[(size_t)j * 64] : (unsigned short)0;
+    for (int j = 0; j < MC; j++) cn[j] = jlo + j < jhi ? p[(size_t)(jlo + j) * 64] : (unsigned short)0;
+    if (SLICED && jlo > 0) pn = park[((size_t)tile * rb_count + ec) * 64 + lane];
   };
   fetch(e0 + wave);
   for (int e = e0 + wave; e < e1; e += WF_NW) {
@@ -172,10 +189,15 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
     unsigned short cc[MC];
 #pragma unroll
     for (int j = 0; j < MC; j++) cc[j] = cn[j];
+    const uint32_t pw = pn;
     fetch(e + WF_NW);
     uint32_t acc[2 * DW];
 #pragma unroll
     for (int x = 0; x < 2 * DW; x++) acc[x] = 0;
+    if (SLICED && jlo > 0) {   // the earlier slices' sums: bytes q0 | q1 << 8 | q2 << 16 | q3 << 24
+      acc[0] = pw & 0x00FF00FFu;
+      acc[1] = (pw >> 8) & 0x00FF00FFu;
+    }
     auto group = [&](const int j, const int cnt4, auto from_regs) {   // quantizers j .. j + cnt4 - 1 (cnt4 <= 4)
       uint32_t xs[DW];
 #pragma unroll
@@ -183,8 +205,8 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
 #pragma unroll
       for (int a = 0; a < WF_NADD; a++) {            // bytes cannot carry: NADD * QMAX <= 255
         if (a < cnt4) {
-          const int c = decltype(from_regs)::value ? (int)cc[(j + a) % MC] : (int)p[(size_t)(j + a) * 64];
-          const QE y = lds[(size_t)(j + a) * k + c];
+          const int c = decltype(from_regs)::value ? (int)cc[(j + a - (SLICED ? jlo : 0)) % MC] : (int)p[(size_t)(j + a) * 64];
+          const QE y = lds[(size_t)(j + a - jlo) * k + c];
 #pragma unroll
           for (int dd = 0; dd < DW; dd++) xs[dd] += reinterpret_cast<const uint32_t *>(&y)[dd];
         }
@@ -198,14 +220,21 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
     if (MQ > 0) {
 #pragma unroll
       for (int g4 = 0; g4 < MQ; g4++) {
-        const int left = m - 4 * g4;                   // (uniform)
-        if (left >= 4) group(4 * g4, 4, std::true_type{});
-        else if (left > 0) group(4 * g4, left, std::true_type{});
+        const int left = jhi - jlo - 4 * g4;           // (uniform)
+        if (left >= 4) group(jlo + 4 * g4, 4, std::true_type{});
+        else if (left > 0) group(jlo + 4 * g4, left, std::true_type{});
       }
     } else {
-      int j = 0;
-      for (; j + 4 <= m; j += 4) group(j, 4, std::false_type{});
-      if (j < m) group(j, m - j, std::false_type{});
+      int j = jlo;
+      for (; j + 4 <= jhi; j += 4) group(j, 4, std::false_type{});
+      if (j < jhi) group(j, jhi - j, std::false_type{});
+    }
+    if (SLICED && jhi < m) {   // not the last slice: park the sums, one byte per query, saturated
+      uint32_t a, b;
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(a) : "v"(acc[0]), "v"(0x00FF00FFu));
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(b) : "v"(acc[1]), "v"(0x00FF00FFu));
+      park[((size_t)tile * rb_count + e) * 64 + lane] = a | (b << 8);
+      continue;
     }
     const int row = rb * 64 + lane;
     const bool valid = row >= row_from && row < row_until;
@@ -320,11 +349,18 @@ __global__ __launch_bounds__(64 * WF_SV_WAVES) void wf_survivors(const uint16_t 
   }
 }
 
-int wf_qw(const gulon_index *ix) {    // queries per 8-bit table entry; 0: the tables do not fit
+int wf_qw(const gulon_index *ix) {    // queries per 8-bit table entry; 0: not even one quantizer's entries fit
   const size_t ent = (size_t)ix->m * ix->k;
   if (ent * 8 <= WF_LDS_BUDGET) return 8;
-  if (ent * 4 <= WF_LDS_BUDGET) return 4;
+  if ((size_t)ix->k * 4 <= WF_LDS_BUDGET) return 4;
   return 0;
+}
+int wf_slice(const gulon_index *ix) {   // quantizers per launch of wf_filter (m: the whole table fits)
+  const int qw = wf_qw(ix);
+  if (qw == 0) return 0;
+  const size_t fit = WF_LDS_BUDGET / ((size_t)ix->k * qw);
+  if (fit >= (size_t)ix->m) return ix->m;
+  return (int)std::min<size_t>(fit, 8);   // (a slice's codes are held in registers while the previous block is looked up)
 }
 
 }  // namespace
@@ -333,8 +369,10 @@ int wf_qw(const gulon_index *ix) {    // queries per 8-bit table entry; 0: the t
 bool wide_filter_eligible(const gulon_index *ix, int B, int K, int rb_total) {
   const ScanTuning &t = tuning_of(ix);
   const size_t table_bytes = (size_t)ix->m * ix->k * sizeof(float);
-  return t.filter && ix->wide && K >= 1 && K <= GULON_MAX_K && wf_qw(ix) != 0 && table_bytes <= 128 * 1024 &&
-         (size_t)B * table_bytes <= (1ull << 30) && rb_total >= 8 * t.filter_min_rb /* 256 K rows by default */;
+  const bool sliced = wf_slice(ix) < ix->m;
+  return t.filter && ix->wide && K >= 1 && K <= GULON_MAX_K && wf_qw(ix) != 0 &&
+         (size_t)B * table_bytes <= (1ull << 30) && rb_total >= 8 * t.filter_min_rb /* 256 K rows by default */ &&
+         (!sliced || (size_t)B * rb_total * 64 <= (2ull << 30) /* the parked byte sums */);
 }
 
 void run_wide_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, int until, bool final_out,
@@ -386,7 +424,8 @@ void run_wide_filter_query(gulon_index *ix, const float *dQ, int B, int K, int f
   // stages, filter.hip: the first stage's survivor rate is ~8 times the second's)
   hipLaunchKernelGGL(wf_table_mins, dim3(m, B), dim3(256), 0, st, ix->tables.p, m, k, ix->qmins.p);
   HIP_CHECK(hipGetLastError());
-  const size_t lds_bytes = tstride;
+  const int jp = wf_slice(ix);                                       // quantizers per filter launch
+  const size_t lds_bytes = jp < m ? (size_t)jp * k * QW : tstride;
   int cus = 256;
   { int dev = 0; HIP_CHECK(hipGetDevice(&dev)); HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); }
   const int resident = std::max(1, (int)(160 * 1024 / lds_bytes));
@@ -410,11 +449,21 @@ void run_wide_filter_query(gulon_index *ix, const float *dQ, int B, int K, int f
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
       hipLaunchKernelGGL(kern, dim3(ngrp, nchunks), dim3(WF_THREADS), lds_bytes, st, ix->wcodes.p, m, k, ix->qtab.p, tstride,
-                         from, until, sb, sc, per, ix->sv_cnt.p, ix->sv_queue.p, cap, ix->fb_tile.p, B);
+                         from, until, sb, sc, per, ix->sv_cnt.p, ix->sv_queue.p, cap, ix->fb_tile.p, B, 0, 0, (uint32_t *)nullptr);
     };
     const int mq = ceil_div(m, 4);
-    if (QW == 8) { if (mq <= 2) go(wf_filter<8, 2>); else if (mq <= 4) go(wf_filter<8, 4>); else go(wf_filter<8, 0>); }
-    else         { if (mq <= 2) go(wf_filter<4, 2>); else if (mq <= 4) go(wf_filter<4, 4>); else go(wf_filter<4, 0>); }
+    if (jp < m) {   // the table in slices of jp quantizers, the byte sums parked in between
+      ix->wpark.ensure((size_t)ngrp * sc * 64);
+      auto kern = jp <= 4 ? wf_filter<4, 1, true> : wf_filter<4, 2, true>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+      for (int j0 = 0; j0 < m; j0 += jp)
+        hipLaunchKernelGGL(kern, dim3(ngrp, nchunks), dim3(WF_THREADS), lds_bytes, st, ix->wcodes.p, m, k, ix->qtab.p, tstride,
+                           from, until, sb, sc, per, ix->sv_cnt.p, ix->sv_queue.p, cap, ix->fb_tile.p, B, j0,
+                           std::min(m, j0 + jp), ix->wpark.p);
+    }
+    else if (QW == 8) { if (mq <= 2) go(wf_filter<8, 2>); else if (mq <= 4) go(wf_filter<8, 4>); else go(wf_filter<8, 0>); }
+    else              { if (mq <= 2) go(wf_filter<4, 2>); else if (mq <= 4) go(wf_filter<4, 4>); else go(wf_filter<4, 0>); }
     HIP_CHECK(hipGetLastError());
     // survivors, exactly (the kernel empties the queues it has read)
     hipLaunchKernelGGL(wf_survivors, dim3(B), dim3(64 * WF_SV_WAVES), 0, st, ix->wcodes.p, m, k, ix->tables.p, ix->row_base,

@@ -140,6 +140,10 @@ def _filtered(g, ix):
     (50000, 32, 8, 4096, 13, 63, 0, None),          # 4 queries per entry (128 KiB), largest K
     (20000, 20, 5, 777, 70, 5, 64, 19999),          # more queries than one launch row, odd k
     (9000, 16, 16, 2048, 5, 10, 0, None),           # 4 queries per entry at m = 16
+    (30000, 32, 16, 4096, 11, 10, 0, None),         # the table in two slices of eight quantizers, byte sums parked
+    (20000, 24, 12, 5000, 7, 10, 100, 19000),       # odd k: slices of 7 + 5 quantizers, sub-range
+    (12000, 16, 8, 16384, 6, 3, 0, None),           # two quantizers per slice: four slices
+    (10000, 8, 4, 32768, 3, 10, 0, None),           # one quantizer per slice (the largest sliced code book)
 ])
 def test_wide_filter_bit_exact(oracle, g, n, d, m, k, B, K, frm, until):
     """The quantized lower-bound filter over 16-bit codes (wide_filter.hip): same ids, order and distance bits as the
