@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
                                                    const float *__restrict__ fin_v, const int *__restrict__ fin_i,
                                                    const float *__restrict__ tau0, int keff, int qmax, int QW,
                                                    uint8_t *__restrict__ qtab /*[Bq/QW][m_pad][256][QW]*/,
-                                                   int *__restrict__ fb_tile, int qt) {
+                                                   int *__restrict__ fb_tile, int qt,
+                                                   const int *__restrict__ slot = nullptr /* table / minima of query q: those of slot[q] */) {
   __shared__ double s_delta[16], s_inv[16];
   __shared__ float s_min[16];
   __shared__ int s_dead[16];
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
         if (j == 0) fb_tile[q / qt] = 1;          // no usable bound: this query is redone exactly
       } else {
         double sum_min = 0.0;
-        for (int jj = 0; jj < m_pad; jj++) sum_min += (double)mins[(size_t)q * m_pad + jj];
+        const int qs = slot ? slot[q] : q;
+        for (int jj = 0; jj < m_pad; jj++) sum_min += (double)mins[(size_t)qs * m_pad + jj];
         const double taup = (double)tau * (1.0 + 2.0 * m_pad * 5.97e-8) * (1.0 + 1e-9);
         double budget = taup - sum_min;
         if (!(budget > 0.0)) budget = 0.0;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
     s_dead[c] = dead;
     s_delta[c] = delta;
     s_inv[c] = 1.0 / delta;
-    s_min[c] = mins[(size_t)q * m_pad + j];
+    s_min[c] = mins[(size_t)((slot && q < B) ? slot[q] : q) * m_pad + j];
   }
   __syncthreads();
   uint32_t out[4];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
       const int s = u4 * 4 + u;
       const int q = g16 * 16 + s;
       const bool have = q < Bp && c < k;
-      const float v = have ? table_at(tables, W, m_pad, q, j, c) : 0.f;
+      const float v = have ? table_at(tables, W, m_pad, slot ? slot[q] : q, j, c) : 0.f;
       int qv = qmax;
       if (have && !s_dead[s] && v == v) {
         double x = ((double)v - (double)s_min[s]) * (1.0 - 8.9e-16);
@@ -311,7 +313,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   QE *qlds = reinterpret_cast<QE *>(qlds_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x, chunk = blockIdx.y;
+  // (MAIN == 2: chunks along x -- consecutive workgroups go to different XCDs, and with the tiles served in the order of
+  // their row limits every XCD then gets the same share of every tile)
+  const int tile = MAIN == 2 ? blockIdx.y : blockIdx.x, chunk = MAIN == 2 ? blockIdx.x : blockIdx.y;
+  const int ntile = MAIN == 2 ? gridDim.y : gridDim.x;
   const int tab = m_pad * 256;   // entries per QW-query group
   {   // every query of this tile already goes to the exact scan: nothing to do here
     const int q_lo = tile * NQG * QW, q_hi = min(B, q_lo + NQG * QW);
@@ -319,6 +324,14 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     if (q_hi > q_lo)
       for (int t = q_lo / qt; t <= (q_hi - 1) / qt; t++) any_live = any_live || fb_tile[t] == 0;
     if (!any_live) return;
+  }
+  // MAIN == 2 (the tie replay's long level, one flag per query, every row block of the range): behind the flags sits
+  // one number per query tile, the last row block any of its queries can still take a row from (replay.hip)
+  int e_limit = e_count;
+  if constexpr (MAIN == 2) {
+    const int nflags = (ntile * NQG * QW + 15) & ~15;
+    e_limit = min(e_count, fb_tile[nflags + tile] - rb_begin + 1);
+    if (chunk * e_per_chunk >= e_limit) return;
   }
   // spreads the queue-tail atomics of one query over NSLOT counters
   const int slot = (chunk * NW + wave) & (NSLOT - 1);
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   __syncthreads();
 
   const int e0 = chunk * e_per_chunk;
-  const int e1 = min(e_count, e0 + e_per_chunk);
+  const int e1 = min(e_limit, e0 + e_per_chunk);
   const Word *cw = reinterpret_cast<const Word *>(codes);
   int mp_p = (e0 + wave) / mp.width, mp_r = (e0 + wave) - mp_p * mp.width;
   auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
@@ -580,17 +593,22 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
 
 template <int QW, int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
-                     int from, int until, int cap, bool main_stage, int B, hipStream_t st, int *fb, int qt) {
+                     int from, int until, int cap, int stage, int B, hipStream_t st, int *fb, int qt) {
   const int W_fp32 = ix->w;
   const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW;
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
   constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
-  auto kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, 0> : filter_kernel<QW, NQG, VEC, NADD, 0, 0>;
+  // stage: 0 a short stage, 1 the main stage (a tag of its own for the profilers), 2 the tie replay's long level
+  // (per-tile row limits behind the flags)
+#define GULON_FILTER_PICK(NG1_) \
+  (stage == 1 ? filter_kernel<QW, NQG, VEC, NADD, 1, NG1_> : stage == 2 ? filter_kernel<QW, NQG, VEC, NADD, 2, NG1_> \
+                                                                         : filter_kernel<QW, NQG, VEC, NADD, 0, NG1_>)
+  auto kern = GULON_FILTER_PICK(0);
   const uint8_t *codes = ix->codes.p, *perm = nullptr;
   if (one_word_form && ix->ng == 1) {
-    kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, one_word_form> : filter_kernel<QW, NQG, VEC, NADD, 0, one_word_form>;
+    kern = GULON_FILTER_PICK(one_word_form);
     if (ix->fcodes.p && tuning_of(ix).filter_order > 0) {   // the conflict-ordered copy of the codes (conflict_order.hip)
-      kern = main_stage ? filter_kernel<QW, NQG, VEC, NADD, 1, 2 * one_word_form> : filter_kernel<QW, NQG, VEC, NADD, 0, 2 * one_word_form>;
+      kern = GULON_FILTER_PICK(2 * one_word_form);
       codes = ix->fcodes.p;
       perm = ix->fperm.p;
     }
@@ -600,7 +618,7 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
   }
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, codes, perm, ix->ng, ix->m_pad,
+  hipLaunchKernelGGL(kern, stage == 2 ? dim3(nchunks, ftiles) : dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, codes, perm, ix->ng, ix->m_pad,
                      ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
                      fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B);
   HIP_CHECK(hipGetLastError());
@@ -660,10 +678,10 @@ int filter_nqg(const gulon_index *ix) {
 }
 
 void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int nchunks, int rb_begin, int e_count,
-                   int e_per_chunk, RbMap mp, int from, int until, int cap, bool main_stage, int B, hipStream_t st,
+                   int e_per_chunk, RbMap mp, int from, int until, int cap, int stage, int B, hipStream_t st,
                    int *fb = nullptr /* tile flags other than the index's own, one per `qt` queries */, int qt = 1) {
 #define GO(W_, Q, V, A) \
-  launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, main_stage, B, st, fb, qt)
+  launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, stage, B, st, fb, qt)
 #define GO_QV(W_, Q, V) do { if (nadd == 4) GO(W_, Q, V, 4); else GO(W_, Q, V, 2); } while (0)
 #define GO_W(W_) do {                                                  \
     if (ix->vec == 16) { if (nqg == 2) GO_QV(W_, 2, 16); else GO_QV(W_, 1, 16); } \
@@ -676,23 +694,64 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 }
 
 // ---- level 2 of the tie replay through the filter (replay_level2_filtered below) ---------------------------------
-// bounds and liveness of the flagged queries: served here iff the batch has enough of them to fill the launch and the
-// query has a finite K-th distance over the earlier rows
-__global__ void rp_filter_bounds(const int *__restrict__ count, int F, int min_flagged, int K,
-                                 const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
-                                 float *__restrict__ tau, int *__restrict__ fb, float *__restrict__ fin_v,
-                                 int *__restrict__ fin_i, int n_pad, const int *__restrict__ done /* [F] or null */) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_pad) return;
+// One workgroup: the flagged queries in the order the long level serves them.  Compact position c -> slot order[c]:
+// the live ones (finite K-th distance over the earlier rows, not served by rp_shortcut, enough flagged queries for a
+// launch) first, by the last row that can still insert (`rlast`, replay.hip) -- a query tile then walks the rows up to
+// ITS largest such row only, and tiles of queries that need no rows at all are skipped -- then the ones left to the
+// segment scan (fb = 1) and the served ones (fb = 2).  tau / fb / fin in compact order; lim[tile] = last row block.
+__global__ __launch_bounds__(1024) void rp_filter_order(const int *__restrict__ count, int F, int min_flagged, int K,
+                                                        const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
+                                                        const int *__restrict__ done, const int *__restrict__ rlast,
+                                                        int row_base, int n_pad, int tile_q, int *__restrict__ order,
+                                                        float *__restrict__ tau, int *__restrict__ fb,
+                                                        float *__restrict__ fin_v, int *__restrict__ fin_i,
+                                                        int *__restrict__ lim /* [n_pad / tile_q] */) {
+  __shared__ unsigned long long key[1024];
+  const int t = threadIdx.x;
   const int nf = min(*count, F);
-  float t = INFINITY;
-  const bool served = done && f < F && done[f] != 0;   // replay.hip, rp_shortcut: nothing left to find for this query
-  if (!served && f < nf && nf >= min_flagged && prefix_c[f] >= K) t = prefix_v[(size_t)f * K + K - 1];
-  const bool live = t < INFINITY;            // (false for NaN too)
-  tau[f] = live ? t : INFINITY;
-  fb[f] = live ? 0 : served ? 2 : 1;         // 1: left to the segment scan
-  fin_v[f] = INFINITY;                       // a one-entry "running list" that never tightens the bound
-  fin_i[f] = INT_MAX;
+  {
+    // class 0: live, by last row block; 1: left to the scan; 2: served; 3: not a flagged query
+    unsigned long long cls = 3, sub = 0;
+    if (t < nf) {
+      const bool served = done && done[t] != 0;
+      const bool live = !served && nf >= min_flagged && prefix_c[t] >= K && prefix_v[(size_t)t * K + K - 1] < INFINITY;
+      cls = live ? 0 : served ? 2 : 1;
+      if (live) {
+        const int last = rlast ? rlast[t] : INT_MAX;
+        sub = last == INT_MAX ? 0x3FFFFFFFull : (unsigned long long)max(0, (last - row_base) >> 6);   // (no result at hand: every row)
+      }
+    }
+    key[t] = (cls << 60) | (sub << 12) | (unsigned long long)t;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= 1024; k2 <<= 1)
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const int o = t ^ j2;
+      if (o > t) {
+        const unsigned long long a = key[t], b = key[o];
+        const bool up = (t & k2) == 0;
+        if ((a > b) == up) { key[t] = b; key[o] = a; }
+      }
+      __syncthreads();
+    }
+  if (t < n_pad) {
+    const unsigned long long kk = key[t];
+    const int cls = (int)(kk >> 60), f = (int)(kk & 0xFFF);
+    const bool live = cls == 0;
+    order[t] = cls == 3 ? 0 : f;
+    tau[t] = live ? prefix_v[(size_t)f * K + K - 1] : INFINITY;
+    fb[t] = live ? 0 : cls == 2 ? 2 : 1;       // (padding slots: 1, but no query behind them)
+    fin_v[t] = INFINITY;                       // a one-entry "running list" that never tightens the bound
+    fin_i[t] = INT_MAX;
+  }
+  if (t < n_pad / tile_q) {                    // the tile's largest limit = that of its last live entry (sorted)
+    int l = -1;
+    for (int c = t * tile_q; c < (t + 1) * tile_q; c++) {
+      const unsigned long long kk = key[c];
+      if ((kk >> 60) == 0) l = (int)min((unsigned long long)INT_MAX, (kk >> 12) & 0xFFFFFFFFFFFFull);
+    }
+    lim[t] = l;
+  }
 }
 
 // the survivors of flagged query f, exactly (the reference's j-ordered unfused sum from the query's fp32 table):
@@ -704,17 +763,25 @@ __global__ __launch_bounds__(256) void rp_filter_emit(const uint8_t *__restrict_
                                                       int *__restrict__ cnt, const int *__restrict__ queue, int cap,
                                                       const int *__restrict__ count, int F, const float *__restrict__ tau,
                                                       int *__restrict__ fb, float *__restrict__ evv, int *__restrict__ evi,
-                                                      int *__restrict__ evcnt, int pool) {
+                                                      int *__restrict__ evcnt, int pool, const int *__restrict__ order,
+                                                      int *__restrict__ scanme /* [slot]: 1 = left to the segment scan */) {
   using Word = typename CodeWord<VEC>::type;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  int mine = lane < NSLOT ? cnt[f * NSLOT + lane] : 0;
+  // compact position fc (queues, bounds, flags) -> slot f (tables, candidate pool)
+  const int fc = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  int mine = lane < NSLOT ? cnt[fc * NSLOT + lane] : 0;
   __syncthreads();                                  // every wave has read the counters
-  if (tid < NSLOT) cnt[f * NSLOT + tid] = 0;
-  if (f >= min(*count, F) || fb[f] != 0) return;
-  if (__ballot(mine > cap) != 0ull) {
-    if (tid == 0) fb[f] = 1;                        // a sub-queue overflowed
+  if (tid < NSLOT) cnt[fc * NSLOT + tid] = 0;
+  if (fc >= min(*count, F)) return;
+  const int f = order[fc];
+  if (fb[fc] != 0) {
+    if (tid == 0) scanme[f] = fb[fc] == 1;
     return;
   }
+  if (__ballot(mine > cap) != 0ull) {
+    if (tid == 0) { fb[fc] = 1; scanme[f] = 1; }    // a sub-queue overflowed
+    return;
+  }
+  if (tid == 0) scanme[f] = 0;
   int incl = mine;
 #pragma unroll
   for (int o = 1; o < NSLOT; o <<= 1) {
@@ -732,9 +799,9 @@ __global__ __launch_bounds__(256) void rp_filter_emit(const uint8_t *__restrict_
     int off = start[0];
 #pragma unroll
     for (int x = 1; x < NSLOT; x++) off = sl == x ? start[x] : off;
-    return queue[((size_t)f * NSLOT + sl) * cap + (e - off)];
+    return queue[((size_t)fc * NSLOT + sl) * cap + (e - off)];
   };
-  const float bound = tau[f];
+  const float bound = tau[fc];
   const float *tq = tables + (size_t)f * m_pad * 256;
   const Word *cw = reinterpret_cast<const Word *>(codes);
   for (int e = tid; e - lane < n; e += 256) {
@@ -911,7 +978,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       // earlier launch and then share the chip once: the event orders launches for throughput, never for results.)
       if (main_stage && !fresh) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
-      launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage, B, st);
+      launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage ? 1 : 0, B, st);
       if (main_stage) HIP_CHECK(hipEventRecord(lane_ev, st));
     }
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
@@ -981,7 +1048,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
 bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi, int from, int until,
                             const float *tables, const float *mins, const float *prefix_v, const int *prefix_c,
                             const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st,
-                            const int *done) {
+                            const int *done, const int *rlast, int *scanme /* [F]: written for every flagged slot */) {
   const ScanTuning &t = tuning_of(ix);
   const int e_count = rb_hi - rb_lo;
   // (the same conditions as filter_eligible; the byte-code kernels only)
@@ -995,18 +1062,22 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   const int cap = std::max(64, t.filter_cap / NSLOT);
   // a launch is worth its fixed costs (quantisation, table staging of every workgroup) from about two query tiles on
   const int min_flagged = 2 * qw;
-  ix->rp_fb.ensure((size_t)Fq); ix->rp_fini.ensure((size_t)Fq);
+  GULON_REQUIRE(F <= 1024, "internal: %d flagged queries per replay round", F);
+  const int tile_q = qw * nqg;
+  ix->rp_fb.ensure((size_t)Fq + ftiles); ix->rp_fini.ensure((size_t)Fq);
   ix->rp_tau.ensure((size_t)Fq); ix->rp_finv.ensure((size_t)Fq);
+  ix->rp_order.ensure((size_t)Fq);
   ix->qtab.ensure((size_t)Fq * ix->m_pad * 256);
   ix->sv_cnt.ensure((size_t)Fq * NSLOT);
   ix->sv_queue.ensure((size_t)Fq * NSLOT * cap);
-  hipLaunchKernelGGL(rp_filter_bounds, dim3(ceil_div(Fq, 256)), dim3(256), 0, st, count, F, min_flagged, K, prefix_v, prefix_c,
-                     ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p, Fq, done);
+  hipLaunchKernelGGL(rp_filter_order, dim3(1), dim3(1024), 0, st, count, F, min_flagged, K, prefix_v, prefix_c, done, rlast,
+                     ix->row_base, Fq, tile_q, ix->rp_order.p, ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p,
+                     ix->rp_fb.p + Fq);
   HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Fq * NSLOT, st));
-  // tables of the flagged queries are [f][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms; queries
-  // beyond F (the padding of the last 16-query group) read no table
+  // tables of the flagged queries are [slot][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms, read
+  // through the order; queries beyond F (the padding of the last 16-query group) read no table
   hipLaunchKernelGGL(qt_quantize, dim3(Fq / 16, ix->m_pad), dim3(256), 0, st, tables, 1, F, ix->m_pad, ix->k, F, mins,
-                     ix->rp_finv.p, ix->rp_fini.p, ix->rp_tau.p, 1, qmax, qw, ix->qtab.p, ix->rp_fb.p, 1);
+                     ix->rp_finv.p, ix->rp_fini.p, ix->rp_tau.p, 1, qmax, qw, ix->qtab.p, ix->rp_fb.p, 1, ix->rp_order.p);
   HIP_CHECK(hipGetLastError());
   const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw;
   const int resident = std::max(1, std::min(2048 / FILTER_THREADS, (int)(160 * 1024 / filter_lds)));
@@ -1016,15 +1087,17 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   const int per = ceil_div(e_count, nc);
   nc = ceil_div(e_count, per);
   const RbMap all{1, 0, 1};
-  launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_lo, e_count, per, all, from, until, cap, false, F, st, ix->rp_fb.p, 1);
+  launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_lo, e_count, per, all, from, until, cap, 2, F, st, ix->rp_fb.p, 1);
   if (ix->vec == 16)
     hipLaunchKernelGGL(rp_filter_emit<16>, dim3(F), dim3(256), 0, st, ix->codes.p, ix->ng, ix->m_pad, tables, ix->row_base,
-                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool);
+                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool,
+                       ix->rp_order.p, scanme);
   else
     hipLaunchKernelGGL(rp_filter_emit<4>, dim3(F), dim3(256), 0, st, ix->codes.p, ix->ng, ix->m_pad, tables, ix->row_base,
-                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool);
+                       ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool,
+                       ix->rp_order.p, scanme);
   HIP_CHECK(hipGetLastError());
-  *only = ix->rp_fb.p;
+  *only = scanme;
   return true;
 }
 

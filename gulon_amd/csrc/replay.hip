@@ -289,7 +289,8 @@ constexpr int RP_KEEP = 2048;
 __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, int lists, long long stride_words, int F,
                                                int C, int lds_pool, int K, int *__restrict__ out_idx,
                                                float *__restrict__ out_dist, int *__restrict__ out_count,
-                                               int *__restrict__ out_flags, unsigned long long *__restrict__ dbg) {
+                                               int *__restrict__ out_flags, unsigned long long *__restrict__ dbg,
+                                               int min_total /* queries with fewer candidates belong to another launch */) {
   extern __shared__ float rp_lds[];
   float *cv = rp_lds;                                          // [lds_pool] candidate distances
   int *ci = reinterpret_cast<int *>(rp_lds + lds_pool);        // [lds_pool] candidate rows
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
       ok = ok && c <= C;
       total += min(c, C);
     }
-    if (!ok || total > lds_pool) continue;   // too many candidates: keeps the (distance, row id) result and its flags
+    if (!ok || total > lds_pool || total < min_total) continue;   // too many candidates: keeps the (distance, row id) result and its flags
     if (dbg && tid == 0 && f == 0) dbg[0] = wall_clock64();
     int n2 = 64;
     while (n2 < total) n2 <<= 1;
@@ -454,11 +455,23 @@ __global__ void rp_shortcut(const int *__restrict__ count, const int *__restrict
                             const float *__restrict__ fin_d, const int *__restrict__ fin_i, const int *__restrict__ fin_c,
                             int first_row /* global id of level 2's first row */, int pool, float *__restrict__ evv,
                             int *__restrict__ evi, int *__restrict__ evcnt, int *__restrict__ done,
-                            int *__restrict__ scanme) {
+                            int *__restrict__ scanme, int *__restrict__ rlast /* last global row id that can insert */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
   const int nf = min(*count, F);
   bool hit = false;
+  {   // no row after the last of the main pass's K best can insert: all K are in the heap by then, its root is at most
+      // the final K-th distance, and a row strictly below that distance is one of the K best itself
+    int last = INT_MAX;
+    if (f < nf) {
+      const int q = list[f];
+      if (q >= 0 && fin_c[q] == K) {
+        last = 0;
+        for (int i = 0; i < K; i++) last = max(last, fin_i[(size_t)q * K + i]);
+      }
+    }
+    rlast[f] = last;
+  }
   if (f < nf && prefix_c[f] >= K) {
     const int q = list[f];
     const float bound = prefix_v[(size_t)f * K + K - 1];
@@ -561,19 +574,21 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
       // the literal heap applies TopKHeap's own test, in row order); batches with enough flagged queries take that
       // road, and the segment scan below only walks the queries left to it (`only`).
       int *only = nullptr;
-      const int *done = nullptr;
+      const int *done = nullptr, *rlast = nullptr;
+      ix->rp_done.ensure((size_t)3 * F);
       if (fin_d && !ix->wide) {
-        ix->rp_done.ensure((size_t)2 * F);
         hipLaunchKernelGGL(rp_shortcut, dim3(ceil_div(F, 256)), dim3(256), 0, st, pk.count(), pk.list(), F, K, ix->rp_prefix.p,
                            ix->rp_precnt.p, fin_d, fin_i, fin_c, (rb_begin + l0 + l1) * 64 + ix->row_base, C, pk.evv(), pk.evi(),
-                           pk.evcnt(), ix->rp_done.p, ix->rp_done.p + F);
+                           pk.evcnt(), ix->rp_done.p, ix->rp_done.p + F, ix->rp_done.p + 2 * F);
         HIP_CHECK(hipGetLastError());
         done = ix->rp_done.p;
         only = ix->rp_done.p + F;
+        rlast = ix->rp_done.p + 2 * F;
       }
       if (recently_flagged >= 32)
         replay_level2_filtered(ix, F, K, rb_begin + l0 + l1, rb_end, from, until, ix->rp_tables.p, ix->rp_mins.p,
-                             ix->rp_prefix.p, ix->rp_precnt.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only, st, done);
+                             ix->rp_prefix.p, ix->rp_precnt.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only, st, done,
+                             rlast, ix->rp_done.p + F);
       scan(rb_begin + l0 + l1, rb_end, per2, segs2, ix->rp_prefix.p, ix->rp_precnt.p, nullptr, nullptr, nullptr, gy, only);
     }
   }
@@ -590,6 +605,28 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
       int hits = 0;
       for (int i = 0; i < h[0]; i++) hits += dn[i] != 0;
       fprintf(stderr, "; long level read off the result for %d of them", hits);
+      std::vector<int> rl((size_t)F);
+      HIP_CHECK(hipMemcpy(rl.data(), ix->rp_done.p + 2 * F, sizeof(int) * (size_t)F, hipMemcpyDeviceToHost));
+      double sum_q = 0, sum_t = 0; int nq = 0, nt = 0;
+      for (int t0 = 0; t0 < h[0]; t0 += 16) {
+        int tmax = -1;
+        for (int i = t0; i < std::min(h[0], t0 + 16); i++) {
+          if (dn[i]) continue;
+          const double fr = rl[i] == INT_MAX ? 1.0 : std::min(1.0, std::max(0.0, (double)(rl[i] - ix->row_base - from) / (double)(until - from)));
+          sum_q += fr; nq++;
+          tmax = std::max(tmax, (int)(fr * 1000));
+        }
+        if (tmax >= 0) { sum_t += tmax / 1000.0; nt++; }
+      }
+      fprintf(stderr, "; last inserting row: mean %.3f of the range over %d queries, mean of the 16-query tile maxima %.3f over %d tiles",
+              nq ? sum_q / nq : 0.0, nq, nt ? sum_t / nt : 0.0, nt);
+      if (recently_flagged >= 32 && ix->rp_fb.n >= (size_t)F + F / 16 && ix->vec == 16 && ix->ng == 1) {   // (tiles of 16 queries)
+        std::vector<int> lim((size_t)F / 16);
+        HIP_CHECK(hipMemcpy(lim.data(), ix->rp_fb.p + F, sizeof(int) * lim.size(), hipMemcpyDeviceToHost));
+        double cover = 0;
+        for (int l : lim) cover += std::max(0.0, std::min(1.0, (double)(l - (rb_begin + l0 + l1) + 1) / (double)std::max(1, l2)));
+        fprintf(stderr, "; in the served order the tiles walk %.3f of (tiles x long-level rows)", cover / std::max<size_t>(1, lim.size()));
+      }
     }
     fprintf(stderr, "\n");
   }
@@ -606,8 +643,17 @@ void replay_apply(const int *packs, int lists, long long stride_words, int F, in
   // a block per flagged query only when the handle has recently seen many of them: every block wants 80+ KiB of LDS,
   // which the other batch's filter kernel does not leave free -- 1024 blocks waiting for it took 1.2 ms for the
   // usual single flagged query (64 blocks: 0.29 ms)
+  // ... and then most of them have few candidates: those go first, with a pool of 2048 -- 32 KiB of LDS, every block
+  // resident at once (0.51 -> 0.1 ms for a batch of 1024 tied queries) -- and the large launch takes what is left
+  int min_total = 0;
+  if (many_flagged && lds_pool > 2048) {
+    const size_t small_lds = (size_t)(2 * 2048 + 2 * RP_KEEP) * sizeof(float);
+    hipLaunchKernelGGL(rp_heap, dim3(std::min(F, 1024)), dim3(256), small_lds, st, packs, lists, stride_words, F, C, 2048, K, d_oi,
+                       d_od, d_oc, d_of, dbgp, 0);
+    min_total = 2049;
+  }
   hipLaunchKernelGGL(rp_heap, dim3(std::min(F, many_flagged ? 1024 : 64)), dim3(256), heap_lds, st, packs, lists, stride_words, F, C, lds_pool,
-                     K, d_oi, d_od, d_oc, d_of, dbgp);
+                     K, d_oi, d_od, d_oc, d_of, dbgp, min_total);
   HIP_CHECK(hipGetLastError());
   if (dbgp) {
     HIP_CHECK(hipStreamSynchronize(st));

@@ -59,7 +59,8 @@ struct gulon_index {
   DevBuf<int> rp_pack, rp_segcnt, rp_segi, rp_precnt, rp_l0i, rp_l0c;
   DevBuf<float> rp_q, rp_tables, rp_segtop, rp_prefix, rp_l0v;
   DevBuf<int> rp_fb, rp_fini;           // level 2 of the replay through the quantized filter (filter.hip)
-  DevBuf<int> rp_done;                  // [2][F]: queries whose level 2 was read off the main pass's result (rp_shortcut)
+  DevBuf<int> rp_done;                  // [3][F]: served by rp_shortcut / left to the segment scan / last row that can insert
+  DevBuf<int> rp_order;                 // the long level's order of the flagged queries (rp_filter_order)
   DevBuf<float> rp_tau, rp_finv, rp_mins;
   // quantized lower-bound filter (filter.hip)
   DevBuf<float> fin_v, qmins, tau0; // running exact (K+1)-lists [Bq][keff]; table minima [Bq][m_pad]; sample bounds
@@ -208,7 +209,7 @@ void launch_merge_enabled(const float *in_v, const int *in_i, int lists, long lo
 bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi, int from, int until,
                             const float *tables, const float *mins, const float *prefix_v, const int *prefix_c,
                             const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st,
-                            const int *done = nullptr);
+                            const int *done, const int *rlast, int *scanme);
 // filter.hip: sample scan -> quantized filter stages -> exact re-evaluation of the survivors.
 bool filter_eligible(const gulon_index *ix, int K, int rb_total);
 // Bounds shared across row shards (sharded.py): phase 1 stops after the sample scan and writes the K+1
