@@ -1452,7 +1452,11 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     std::vector<int> act;
     for (int p = 0; p < np; p++) if (!P[p].done) act.push_back(p);
     if (act.empty()) break;
-    // one batched update for all active problems, then every problem's assign on its own stream
+    // one batched update for all active problems, then every problem's assign on its own stream.  (Measured and
+    // dropped: the update in staggered groups of problems -- a group's chains under the next group's regrouping, its
+    // assign under the next chains, so that the first assign starts after a quarter of the update: 12 iterations at
+    // BASELINE config 3 take 0.66 s with one group, 0.71 / 0.79 / 0.93 s with 2 / 4 / 8 -- the memory-bound regrouping
+    // and the assign slow each other down by more than the overlap saves.)
     std::vector<UpdDesc> descs;
     for (int p : act)
       descs.push_back(make_upd_desc(P[p].ws, P[p].xs.p, sdim[p], n, k, 0, sdim[p], P[p].a_prev.p, P[p].c_next.p));
