@@ -149,6 +149,7 @@ __device__ __forceinline__ void scan_body(
     int row_from, int row_until, int row_base, int rb_begin, int e_count, int e_per_chunk, RbMap mp, int nchunks,
     int keff, float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,
     int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi,
+    const uint8_t *__restrict__ perm /* non-null: `codes` is the conflict-ordered copy (conflict_order.hip), perm its row order */,
     const int tile /* query tile of this pass */, unsigned long long *__restrict__ dbg) {
   constexpr int QT = W * NSUB;
   // optional timeline (GULON_SCAN_TIMELINE=1): 4 stamps per workgroup, 100 MHz wall clock
@@ -272,7 +273,8 @@ __device__ __forceinline__ void scan_body(
     }
 
     const int row = rb * 64 + lane;
-    const bool valid = row >= row_from && row < row_until;
+    // (ordered copy: which row a lane holds is looked up only when some lane has a candidate)
+    const bool valid = perm != nullptr || (row >= row_from && row < row_until);
     unsigned long long masks[QT];
     unsigned long long any = 0;
 #pragma unroll
@@ -282,14 +284,21 @@ __device__ __forceinline__ void scan_body(
       any |= mk;
     }
     if (any) {
+      int place = lane;
+      unsigned long long in_range = ~0ull;
+      if (perm) {
+        place = perm[(size_t)rb * 64 + lane];
+        const int prow = rb * 64 + place;
+        in_range = __ballot(prow >= row_from && prow < row_until);
+      }
 #pragma unroll
       for (int q = 0; q < QT; q++) {
-        unsigned long long mk = masks[q];
+        unsigned long long mk = masks[q] & in_range;
         while (mk) {
           int l = __ffsll((long long)mk) - 1;
           mk &= mk - 1;
           float cv = readlane_f(acc[q], l);
-          int cr = rb * 64 + l + row_base;
+          int cr = rb * 64 + readlane_i(place, l) + row_base;
           if (peel && !(cv > lbq[q] || (cv == lbq[q] && cr > lbiq[q]))) continue;
           if (cnt[q] < keff || wl[q].accepts(cv, cr)) {
             wl[q].insert(cv, cr, keff, lane);
@@ -351,10 +360,10 @@ __device__ __forceinline__ void scan_body(
   const uint8_t *__restrict__ codes, int ng, int m_pad, const float4 *__restrict__ tables, int row_from,           \
       int row_until, int row_base, int rb_begin, int e_count, int e_per_chunk, RbMap mp, int nchunks, int keff,     \
       float *__restrict__ part_v, int *__restrict__ part_i, unsigned *__restrict__ gtau, int tau_off4,              \
-      int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi
+      int prune_from, const float *__restrict__ lbv, const int *__restrict__ lbi, const uint8_t *__restrict__ perm
 #define GULON_SCAN_ARGS                                                                                            \
   codes, ng, m_pad, tables, row_from, row_until, row_base, rb_begin, e_count, e_per_chunk, mp, nchunks, keff,      \
-      part_v, part_i, gtau, tau_off4, prune_from, lbv, lbi
+      part_v, part_i, gtau, tau_off4, prune_from, lbv, lbi, perm
 
 // workgroup (x, y) = query tile x (fastest: the tiles of one chunk run together) x chunk y of the row blocks
 template <int W, int NSUB, int VEC, int THREADS, bool PRUNE>
@@ -692,7 +701,7 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
       hipLaunchKernelGGL(kern, dim3(std::max(1, std::min(grid_x, ntiles)), nchunks), dim3(SCAN_THREADS), lds_bytes, st,
                          ix->codes.p, ix->ng, ix->m_pad, reinterpret_cast<const float4 *>(ix->tables.p), from, until,
                          ix->row_base, rb_begin, e_count, e_per_chunk, mp, nchunks, keff, ix->part_v.p, ix->part_i.p,
-                         ix->gtau.p, tau_off4, prune_from, lbv, lbi, tile_enable, tile_div, ntiles, hint);
+                         ix->gtau.p, tau_off4, prune_from, lbv, lbi, (const uint8_t *)nullptr, tile_enable, tile_div, ntiles, hint);
       HIP_CHECK(hipGetLastError());
       return;
     } else {
@@ -702,10 +711,14 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
   auto kern = scan_kernel<W, NSUB, VEC, SCAN_THREADS, PRUNE>;
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,
+  // one-word codes: the exact scan's table gathers are the same ds_read_b128 of 256 x 16-byte entries per quantizer as
+  // the filter's, so the conflict-ordered copy serves it too (13 of its 16 quantizers were ordered for)
+  const bool ordered = VEC == 16 && ix->ng == 1 && ix->fcodes.p && tuning_of(ix).filter_order > 0;
+  hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ordered ? ix->fcodes.p : ix->codes.p,
+                     ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, e_count,
                      e_per_chunk, mp, nchunks, keff, ix->part_v.p, ix->part_i.p, ix->gtau.p, tau_off4, prune_from, lbv,
-                     lbi, dbg);
+                     lbi, ordered ? ix->fperm.p : (const uint8_t *)nullptr, dbg);
   HIP_CHECK(hipGetLastError());
   if (dbg) {   // debugging aid: synchronous dump of the per-workgroup timeline
     HIP_CHECK(hipStreamSynchronize(st));
