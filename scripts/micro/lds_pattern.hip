@@ -3,6 +3,7 @@
 // 16 waves per CU so that the LDS pipe is the bound; one launch per pattern, patterns printed with their time so that a
 // cost model can be fitted offline (scripts/micro/lds_pattern_fit.py).
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/lds_pattern.hip -o /tmp/lds_pattern && /tmp/lds_pattern > patterns.txt
+//   lds_pattern pat|swap [16|8|4]: the address patterns / the lane exchanges, for ds_read_b128 / b64 / b32
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -11,30 +12,36 @@
 #include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+template <typename E>   // uint4: ds_read_b128, uint2: ds_read_b64, uint32_t: ds_read_b32; idx in entries of sizeof(E)
 __global__ __launch_bounds__(1024) void probe(const int *__restrict__ idx, int iters, uint4 *__restrict__ out) {
-  extern __shared__ uint4 lds[];   // 8192 entries
+  extern __shared__ uint4 lds_raw[];   // 128 KiB
+  E *lds = reinterpret_cast<E *>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int e = tid; e < 8192; e += 1024) lds[e] = make_uint4(e, e * 3, e * 5, e * 7);
+  for (int e = tid; e < 8192; e += 1024) lds_raw[e] = make_uint4(e, e * 3, e * 5, e * 7);
   __syncthreads();
   int a = idx[lane];
-  uint4 acc = make_uint4(0, 0, 0, 0);
+  uint32_t acc = 0;
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       asm volatile("" : "+v"(a));
-      const uint4 x = lds[a];
-      acc.x += x.x; acc.y ^= x.y; acc.z += x.z; acc.w ^= x.w;
+      const E x = lds[a];
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&x);
+#pragma unroll
+      for (int c = 0; c < (int)(sizeof(E) / 4); c++) acc += w[c];
     }
   }
-  out[(size_t)blockIdx.x * 1024 + tid] = acc;
+  out[(size_t)blockIdx.x * 1024 + tid] = make_uint4(acc, 0, 0, 0);
 }
 
 int main(int argc, char **argv) {
   const bool swaps = argc > 1 && !strcmp(argv[1], "swap");
+  const int width = argc > 2 ? atoi(argv[2]) : 16;   // bytes per entry: 16 (default), 8 or 4
   const int blocks = 256, iters = swaps ? 150 : 400;
   int *d_idx; uint4 *o;
   CK(hipMalloc(&d_idx, 64 * 4)); CK(hipMalloc(&o, (size_t)blocks * 1024 * sizeof(uint4)));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(probe), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  auto kern = width == 16 ? probe<uint4> : width == 8 ? probe<uint2> : probe<uint32_t>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
   std::vector<std::vector<int>> pats;
   std::vector<const char *> names;
   auto add = [&](const char *nm, std::vector<int> p) { pats.push_back(p); names.push_back(nm); };
@@ -75,7 +82,7 @@ int main(int argc, char **argv) {
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(probe, dim3(blocks), dim3(1024), 131072, 0, d_idx, iters, o);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), 131072, 0, d_idx, iters, o);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep > 0 && ms < best) best = ms;

@@ -2,7 +2,7 @@
 
   build/expt/lds_pattern      > patterns.txt     (262 address patterns: name, cycles, 64 entry indices)
   build/expt/lds_pattern swap > swaps.txt        (linear addresses with two lanes exchanged)
-  python3 scripts/micro/lds_pattern_fit.py patterns.txt swaps.txt
+  python3 scripts/micro/lds_pattern_fit.py patterns.txt swaps.txt [16|8|4]      (bytes per entry: ds_read_b128 / b64 / b32)
 
 1. swaps.txt gives the lane groups: exchanging the addresses of lanes i and j of a conflict-free pattern costs
    nothing iff both are served together.  Result: {0-3, 12-15, 20-23, 24-27}, {4-7, 8-11, 16-19, 28-31}, and both + 32.
@@ -10,6 +10,10 @@
    column = entry index mod 16) + 0.5   -- rms error 0.27 cycles over all patterns, correlation 0.998 on random ones
    (mean 11.7 + 0.5 predicted, 12.1 measured); the only misfit is the floor of 5.4 cycles where the model says 4.
 conflict_order.hip orders the rows of the filter's code copy by this model.
+3. ds_read_b64 / ds_read_b32 (`lds_pattern swap 8`, `pat 8`, ... 4): the lanes are served in TWO groups, 0-31 and 32-63;
+   the bank column is the entry index mod 32 in both cases -- 8-byte entries: address bits [7:3], 256 bytes of banks;
+   4-byte entries: address bits [6:2], i.e. 32 banks of 4 bytes (mod 64 does not fit: rms 2.6) -- and the cost the same
+   sum of fullest columns: rms error 0.21 / 0.19 cycles, random 256-entry tables 7.1 / 6.7 cycles, conflict-free 3.8 / 3.4.
 """
 import sys
 import numpy as np
@@ -22,18 +26,24 @@ def groups_from_swaps(path):
         _, i, j = f[0].split("_")
         t[int(i), int(j)] = t[int(j), int(i)] = float(f[1])
     lo = np.nanmin(t)
-    groups, seen = [], set()
+    parent = list(range(64))     # lanes served together: connected components of "the exchange costs nothing"
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
     for i in range(64):
-        if i in seen:
-            continue
-        same = {i} | {j for j in range(64) if not np.isnan(t[i, j]) and t[i, j] < lo + 0.7}
-        # lanes with the same column as i (never exchanged) belong to other groups
-        groups.append(sorted(same))
-        seen |= same
-    return groups
+        for j in range(i + 1, 64):
+            if not np.isnan(t[i, j]) and t[i, j] < lo + 0.4:
+                parent[find(i)] = find(j)
+    comps = {}
+    for i in range(64):
+        comps.setdefault(find(i), []).append(i)
+    return sorted(comps.values())
 
 
-def fit(path, groups):
+def fit(path, groups, columns=16):
     rows = [line.split() for line in open(path)]
     names = [r[0] for r in rows]
     t = np.array([float(r[1]) for r in rows])
@@ -42,7 +52,7 @@ def fit(path, groups):
     def fullest(idx):
         per = {}
         for a in set(idx):
-            per[a % 16] = per.get(a % 16, 0) + 1
+            per[a % columns] = per.get(a % columns, 0) + 1
         return max(per.values())
     pred = np.array([sum(fullest([p[lane] for lane in g]) for g in groups) for p in pats], float)
     a, b = np.polyfit(pred, t, 1)
@@ -56,4 +66,5 @@ if __name__ == "__main__":
     g = groups_from_swaps(sys.argv[2])
     for grp in g:
         print("group:", grp)
-    fit(sys.argv[1], g)
+    width = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    fit(sys.argv[1], g, {16: 16, 8: 32, 4: 32}[width])
