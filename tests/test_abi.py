@@ -65,3 +65,29 @@ def test_product_path_has_no_oracle_import():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "gulon_oracle" not in txt and "go_" + "kmeans" not in txt, f
+
+
+def test_filter_kernels_keep_their_code_words_in_registers():
+    """Every instantiation of the quantized filter's kernel compiles without scratch memory.  (Round 2 refactored its
+    inner loop into a lambda that overwrote a captured code word: the multi-word forms -- m = 32, 48, 64 ... -- then kept
+    that word in scratch, 32 bytes per lane, and BASELINE config 5 ran 13 % slower until a profile showed it.)"""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-c",
+           os.path.join(ROOT, "gulon_amd", "csrc", "filter.hip"), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    name, seen, spilled = None, 0, []
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and "filter_kernel" in name:
+            seen += 1
+            if int(m.group(1)) != 0:
+                spilled.append((name, int(m.group(1))))
+    assert seen >= 24, seen
+    assert not spilled, spilled
