@@ -356,7 +356,8 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     advance(mp_p, mp_r);
     const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
     Word w = w_first;
-    if (e + NW < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+    // (unconditional: the last iteration re-reads its own block -- a conditional load costs a copy of the word back)
+    w_first = cw[((size_t)(e + NW < e1 ? block_of(mp_p, mp_r) : rb) * ng) * 64 + lane];
 
     // acc[s][2*dd]   : 16-bit sums of queries 4dd (low half) and 4dd+2 (high half) of group s
     // acc[s][2*dd+1] : queries 4dd+1 and 4dd+3
