@@ -194,13 +194,14 @@ def test_wide_filter_unusable_bounds_fall_back(oracle, g):
     ix.close()
 
 
-def test_wide_filter_sharded_equals_unsharded(g):
+@pytest.mark.parametrize("n,d,m,k,B,K", [(90000, 32, 8, 600, 20, 10),
+                                         (60000, 32, 16, 4096, 9, 10)])      # the 8-bit tables in two slices
+def test_wide_filter_sharded_equals_unsharded(g, n, d, m, k, B, K):
     from test_gpu_shared_bounds import _same, sharded_query
     import ctypes as C
     from gulon_amd import native as N
     N.check(N.lib().gulon_scan_tuning(b"GULON_FILTER_MIN_RB", 4))
     try:
-        n, d, m, k, B, K = 90000, 32, 8, 600, 20, 10
         rng = np.random.default_rng(8)
         cents = rng.standard_normal(k * d).astype(np.float32)
         idx = rng.integers(0, k, (m, n)).astype(np.int32)
