@@ -705,7 +705,7 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
 __global__ __launch_bounds__(1024) void rp_filter_order(const int *__restrict__ count, int F, int min_flagged, int K,
                                                         const float *__restrict__ prefix_v, const int *__restrict__ prefix_c,
                                                         const int *__restrict__ done, const int *__restrict__ rlast,
-                                                        int row_base, int n_pad, int tile_q, int *__restrict__ order,
+                                                        int row_base, int n_pad, int tile_q, int ntiles, int *__restrict__ order,
                                                         float *__restrict__ tau, int *__restrict__ fb,
                                                         float *__restrict__ fin_v, int *__restrict__ fin_i,
                                                         int *__restrict__ lim /* [n_pad / tile_q] */) {
@@ -747,9 +747,9 @@ __global__ __launch_bounds__(1024) void rp_filter_order(const int *__restrict__ 
     fin_v[t] = INFINITY;                       // a one-entry "running list" that never tightens the bound
     fin_i[t] = INT_MAX;
   }
-  if (t < n_pad / tile_q) {                    // the tile's largest limit = that of its last live entry (sorted)
+  if (t < ntiles) {                            // the tile's largest limit = that of its last live entry (sorted)
     int l = -1;
-    for (int c = t * tile_q; c < (t + 1) * tile_q; c++) {
+    for (int c = t * tile_q; c < min(n_pad, (t + 1) * tile_q); c++) {
       const unsigned long long kk = key[c];
       if ((kk >> 60) == 0) l = (int)min((unsigned long long)INT_MAX, (kk >> 12) & 0xFFFFFFFFFFFFull);
     }
@@ -1074,7 +1074,7 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   ix->sv_cnt.ensure((size_t)Fq * NSLOT);
   ix->sv_queue.ensure((size_t)Fq * NSLOT * cap);
   hipLaunchKernelGGL(rp_filter_order, dim3(1), dim3(1024), 0, st, count, F, min_flagged, K, prefix_v, prefix_c, done, rlast,
-                     ix->row_base, Fq, tile_q, ix->rp_order.p, ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p,
+                     ix->row_base, Fq, tile_q, ftiles, ix->rp_order.p, ix->rp_tau.p, ix->rp_fb.p, ix->rp_finv.p, ix->rp_fini.p,
                      ix->rp_fb.p + Fq);
   HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Fq * NSLOT, st));
   // tables of the flagged queries are [slot][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms, read

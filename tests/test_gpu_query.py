@@ -138,6 +138,7 @@ def test_exact_heap_replay_whole_batch_flagged(oracle, g):
     (300000, 32, 8, 256, 10, 100, 400, 0, None),          # every query tied, m = 8 (4-byte code words)
     (260000, 64, 16, 256, 5, 70, 300, 1000, 255000),      # m = 16 (the headline kernel form), sub-range
     (200000, 32, 8, 256, 63, 40, 100, 0, None),           # largest K of one scan
+    (200000, 80, 40, 256, 10, 40, 100, 0, None),          # m = 40: eight queries per table entry, an odd number of query tiles
 ])
 def test_exact_heap_replay_many_flagged_long_range(oracle, g, n, d, m, k, K, B, nbase, frm, until):
     """Enough flagged queries and rows for the long level of the replay to go through the quantized filter
