@@ -195,7 +195,12 @@ def main():
     torch.cuda.set_device(local_rank)
     N.check(N.lib().gulon_set_device(local_rank))
     dist = None
-    rehearse = world == 1 and bool(os.environ.get("GULON_BENCH_REHEARSE"))   # one rank, real RCCL calls
+    # GULON_BENCH_REHEARSE=1: one rank, the multi-rank pipeline with real RCCL calls over all --rows rows;
+    # GULON_BENCH_REHEARSE=N > 1: this process is rank 0 of N -- 1/N of the rows, N lists per exchange, the other
+    # ranks' slots of every gather prefilled once with what they send for the bench queries (ShardedIndex.prefill)
+    rehearse = world == 1 and bool(os.environ.get("GULON_BENCH_REHEARSE"))
+    emu = int(os.environ.get("GULON_BENCH_REHEARSE", "0") or 0) if rehearse else 0
+    emu = emu if emu > 1 else 0
     if rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -234,7 +239,7 @@ def main():
         enc = pq.encode(dm)
         t3 = time.perf_counter()
         note("encoded")
-        lo, hi = shard_bounds(n, world, rank)
+        lo, hi = shard_bounds(n, emu if emu else world, rank)
         shard = local_shard(pq, enc, lo, hi)
     else:
         # quantizer-partitioned training + encoding, codebooks/codes all-gathered, rows re-sharded
@@ -256,7 +261,7 @@ def main():
     # (gulon_index_context_create: its own scratch, the same codes and codebooks)
     engines = [HipEngine(pq, shard, lo, dev)]
     engines += [HipEngine(pq, shard, lo, dev, parent=engines[0]) for _ in range(nfl - 1)]
-    shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse) for e in engines]
+    shardeds = [ShardedIndex(e, n, rank, world, dist, rehearse, emulate_world=emu) for e in engines]
     if collective:
         # side streams only: work on the legacy default stream serialises with the collectives' stream
         # (rehearsal, two batches in flight: 0.716 ms per step with the default stream among them, 0.615 without)
@@ -271,6 +276,19 @@ def main():
     qrows = sample_rows(n, B, 0)
     Qh = dm.get_rows(qrows)
     Q = torch.from_numpy(Qh).to(dev)
+
+    if emu:
+        others = []
+        for r in range(1, emu):
+            rlo, rhi = shard_bounds(n, emu, r)
+            others.append(HipEngine(pq, local_shard(pq, enc, rlo, rhi), rlo, dev))
+        shardeds[0].prefill(Q, B, K, others)
+        for s_ in shardeds[1:]:
+            s_.copy_prefill(shardeds[0], B, K)
+        for e in others:
+            e.index.close()
+        del others
+        note(f"rank 0 of {emu}: the other ranks' slots prefilled")
 
     step_no = [0]
 
@@ -311,11 +329,18 @@ def main():
     for e in engines:
         N.check(L.gulon_index_profile(e.index._h, 1))
     barrier()
+    if os.environ.get("GULON_HOST_PROFILE"):
+        ShardedIndex.host_profile = {"_last": time.perf_counter()}
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
     enqueue_s = time.perf_counter() - t_start          # host time to enqueue K steps (diagnostic)
+    if ShardedIndex.host_profile is not None and rank == 0:
+        hp, ShardedIndex.host_profile = ShardedIndex.host_profile, None
+        for name, sec in sorted(hp.items(), key=lambda kv: -kv[1] if kv[0] != "_last" else 0):
+            if name != "_last":
+                print(f"[host] {sec / args.steps * 1e6:8.1f} us/step  {name}", file=sys.stderr)
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -397,7 +422,11 @@ def main():
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
     }
     if rehearse:
-        result["config"]["rehearsal"] = "one rank through the multi-rank pipeline (RCCL all-gathers of one list)"
+        result["config"]["rehearsal"] = (
+            f"rank 0 of {emu}: {nloc} of the {n} rows, {emu} lists per exchange (RCCL all-gathers over a one-rank group "
+            f"move this rank's slot; the other ranks' bounds, lists and tie candidates for these queries were computed "
+            f"once from their shards)" if emu else
+            "one rank through the multi-rank pipeline (RCCL all-gathers of one list)")
 
     if rank == 0:
         if not args.no_recall:
@@ -408,7 +437,7 @@ def main():
             result["recall_seconds"] = time.perf_counter() - t
             result["tie_flagged_queries"] = int((res_flg != 0).sum())
             note("recall done")
-        if world == 1 and enc is not None and not args.no_extras:
+        if world == 1 and enc is not None and not args.no_extras and not rehearse:
             result["extras"] = extras(args, g, N, L, torch, dev, HipEngine, ShardedIndex, local_shard, recall_at_k,
                                       sample_rows, dm, pq, shard, shardeds, streams, engines, Q, note)
         if world == 1 and enc is not None and not args.no_cpu_baseline:

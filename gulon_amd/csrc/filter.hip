@@ -31,7 +31,11 @@ namespace gulon {
 namespace {
 
 constexpr size_t FILTER_LDS_BUDGET = 144 * 1024;
-constexpr int FILTER_THREADS = 1024;
+#ifndef GULON_FILTER_THREADS
+#define GULON_FILTER_THREADS 1024
+#endif
+constexpr int FILTER_THREADS = GULON_FILTER_THREADS;   // filter_kernel's workgroup
+constexpr int BOUND_THREADS = 1024;                     // bound_tables' workgroup
 constexpr int NSLOT = 16;   // survivor sub-queues per query (workgroups of different chunks use different ones)
 
 __device__ inline uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {   // per 16-bit half: max(a - b, 0)
@@ -45,16 +49,15 @@ __device__ inline float table_at(const float *__restrict__ tables, int W, int m_
   return tables[(((size_t)(q / W) * m_pad + j) * 256 + c) * W + q % W];
 }
 
-// ---- per-batch reset of the small scratch arrays in one launch ----------------------------------
-__global__ void filter_reset(unsigned *__restrict__ gtau, int n_gtau, int *__restrict__ fb_tile, int n_fb,
-                             int *__restrict__ sv_cnt, int n_cnt) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_gtau) gtau[t] = 0x7F800000u;   // +inf
-  if (t < n_fb) fb_tile[t] = 0;
-  if (t < n_cnt) sv_cnt[t] = 0;
-}
-
-// ---- quantize the tables of one 16-query group against the current bounds --------------------
+#ifdef GULON_FILTER_STAMPS
+// experiment builds only (scripts/variant.sh ... -DGULON_FILTER_STAMPS): every wave of every main-stage workgroup records
+// when it started, had its tables staged and left its row loop (100 MHz wall clock) and where it ran
+// (HW_ID, XCC_ID) -> GULON_FILTER_STAMPS=<file> dumps [workgroup][52] uint64 after every main-stage launch
+__device__ unsigned long long *g_filter_stamps;
+__device__ unsigned long long *g_qt_stamps;   // qt_quantize: [workgroup][4] = entry, bounds ready, loop done, 0
+__device__ unsigned long long *g_bt_stamps;   // bound_tables: [workgroup][8] = entry, tables built, scan done, end, + 4 inside the table build
+#endif
+// ---- quantize the tables of four queries (one dword of an entry) against the current bounds ----
 __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tables, int W, int Bp, int m_pad, int k,
                                                    int B, const float *__restrict__ mins,
                                                    const float *__restrict__ fin_v, const int *__restrict__ fin_i,
@@ -62,27 +65,53 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
                                                    uint8_t *__restrict__ qtab /*[Bq/QW][m_pad][256][QW]*/,
                                                    int *__restrict__ fb_tile, int qt,
                                                    const int *__restrict__ slot = nullptr /* table / minima of query q: those of slot[q] */) {
-  __shared__ double s_delta[16], s_inv[16];
-  __shared__ float s_min[16];
-  __shared__ int s_dead[16];
-  const int g16 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
-  if (c < 16) {
-    const int q = g16 * 16 + c;
+  // One workgroup = the 256 centroids of ONE quantizer for FOUR queries (one dword of a table entry): 4 x the
+  // workgroups of a 16-query form with a quarter of the serial work each -- the kernel is latency, not throughput
+  // (20 us per launch on a 1.25 M-row shard as 1024 workgroups that walked their 16 queries in four dependent steps).
+  __shared__ float s_inv32[4];
+  __shared__ float s_min[4];
+  __shared__ int s_dead[4];
+  __shared__ float s_mins[4 * 144];                // the four queries' table minima (m_pad <= 144)
+  const int g4 = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
+#ifdef GULON_FILTER_STAMPS
+  const unsigned long long qs0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // everything the workgroup reads is requested up front -- its table entries, the 4 x m_pad minima (coalesced) and
+  // each query's bound -- so that the memory round trips overlap
+  float vv[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int q = g4 * 4 + u;
+    vv[u] = (q < Bp && c < k) ? table_at(tables, W, m_pad, slot ? slot[q] : q, j, c) : 0.f;
+  }
+  for (int e = c; e < 4 * m_pad; e += 256) {
+    const int qq = e / m_pad, jj = e - qq * m_pad, q = g4 * 4 + qq;
+    s_mins[e] = q < B ? mins[(size_t)(slot ? slot[q] : q) * m_pad + jj] : 0.f;
+  }
+  float tau = INFINITY;
+  int fb = 1;
+  if (c < 4 && g4 * 4 + c < B) {
+    const int q = g4 * 4 + c;
+    // bound = the sample's, tightened by the running list once that is full
+    const float t0 = tau0[q], fv = fin_v[(size_t)q * keff + keff - 1];
+    const int fi = fin_i[(size_t)q * keff + keff - 1];
+    fb = fb_tile[q / qt];
+    tau = fi != INT_MAX ? fminf(t0, fv) : t0;
+  }
+  __syncthreads();
+  if (c < 4) {
+    const int q = g4 * 4 + c;
     int dead = 1;
     double delta = 1.0;
     if (q < B) {
-      // bound = the sample's, tightened by the running list once that is full
-      float tau = tau0[q];
-      if (fin_i[(size_t)q * keff + keff - 1] != INT_MAX) tau = fminf(tau, fin_v[(size_t)q * keff + keff - 1]);
-      if (fb_tile[q / qt] != 0) {
+      if (fb != 0) {
         // this query tile already goes to the exact scan (unusable bound, queue overflow, or a
         // first stage that let too many rows through): nothing of it is filtered any more
       } else if (!(tau < INFINITY)) {
         if (j == 0) fb_tile[q / qt] = 1;          // no usable bound: this query is redone exactly
       } else {
         double sum_min = 0.0;
-        const int qs = slot ? slot[q] : q;
-        for (int jj = 0; jj < m_pad; jj++) sum_min += (double)mins[(size_t)qs * m_pad + jj];
+        for (int jj = 0; jj < m_pad; jj++) sum_min += (double)s_mins[c * m_pad + jj];
         const double taup = (double)tau * (1.0 + 2.0 * m_pad * 5.97e-8) * (1.0 + 1e-9);
         double budget = taup - sum_min;
         if (!(budget > 0.0)) budget = 0.0;
@@ -92,51 +121,51 @@ __global__ __launch_bounds__(256) void qt_quantize(const float *__restrict__ tab
       }
     }
     s_dead[c] = dead;
-    s_delta[c] = delta;
-    s_inv[c] = 1.0 / delta;
-    s_min[c] = mins[(size_t)((slot && q < B) ? slot[q] : q) * m_pad + j];
+    // 1 / delta for the fp32 levels below: rounded to fp32 (<= 2^-24 relative), then shrunk by 2^-21; a delta so
+    // small that the reciprocal overflows fp32 leaves +inf -> every entry above its minimum gets the top level (valid:
+    // levels only ever round down from x / delta, and the top level is what min(QMAX, .) would give)
+    float inv32 = (float)(1.0 / delta);
+    inv32 = inv32 < INFINITY ? inv32 * (1.0f - 4.76837158e-7f) : 3.0e38f;
+    s_inv32[c] = inv32;
+    s_min[c] = s_mins[c * m_pad + j];
   }
   __syncthreads();
-  uint32_t out[4];
+#ifdef GULON_FILTER_STAMPS
+  const unsigned long long qs1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // The level of an entry in fp32, rounded DOWN for certain: x = T - min (one rounding, <= 2^-24 relative), times the
+  // reciprocal of delta, which the prologue shrank by 2^-21 (fp64 -> fp32, the shrinking, the subtraction, the product: four roundings of
+  // 2^-24 each = 2^-22) -- they cannot carry the product above the real quotient x / delta, so  level * delta <= x  holds as the bound
+  // needs it (the fp64 form of this -- conversions, a guard loop -- was a dozen half- and quarter-rate instructions
+  // per entry on a vector ALU that another batch's main stage keeps 90 % busy).  Levels are < 256: exact in fp32.
+  uint32_t word = 0;
 #pragma unroll
-  for (int u4 = 0; u4 < 4; u4++) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int s = u4 * 4 + u;
-      const int q = g16 * 16 + s;
-      const bool have = q < Bp && c < k;
-      const float v = have ? table_at(tables, W, m_pad, slot ? slot[q] : q, j, c) : 0.f;
-      int qv = qmax;
-      if (have && !s_dead[s] && v == v) {
-        double x = ((double)v - (double)s_min[s]) * (1.0 - 8.9e-16);
-        if (x < 0.0) x = 0.0;
-        const double r = x * s_inv[s];                       // ~ x / delta; any level with level * delta <= x is valid
-        if (r < (double)qmax) {
-          qv = (int)r;                                       // floor: r >= 0
-          while (qv > 0 && (double)qv * s_delta[s] > x) qv--;   // guard the rounding of the reciprocal
-        }
-      }
-      word |= (uint32_t)qv << (8 * u);
+  for (int u = 0; u < 4; u++) {
+    const int q = g4 * 4 + u;
+    const bool have = q < Bp && c < k;
+    const float v = vv[u];
+    int qv = qmax;
+    if (have && !s_dead[u] && v == v) {
+      float x = v - s_min[u];
+      if (!(x > 0.f)) x = 0.f;
+      const float r = x * s_inv32[u];
+      if (r < (float)qmax) qv = (int)r;                      // floor: r >= 0
     }
-    out[u4] = word;
+    word |= (uint32_t)qv << (8 * u);
   }
-  // queries g16*16 .. +15 -> entries of QW bytes: [q / QW][j][c][q % QW]
-  if (QW == 16) {
-    reinterpret_cast<uint4 *>(qtab)[((size_t)g16 * m_pad + j) * 256 + c] = make_uint4(out[0], out[1], out[2], out[3]);
-  } else if (QW == 8) {
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-      reinterpret_cast<uint2 *>(qtab)[((size_t)(g16 * 2 + h) * m_pad + j) * 256 + c] = make_uint2(out[2 * h], out[2 * h + 1]);
-  } else {
-#pragma unroll
-    for (int h = 0; h < 4; h++)
-      reinterpret_cast<uint32_t *>(qtab)[((size_t)(g16 * 4 + h) * m_pad + j) * 256 + c] = out[h];
+  // queries 4 g4 .. + 3 -> dword (4 g4 % QW) / 4 of entry [4 g4 / QW][j][c] (QW bytes per entry)
+  const int grp = (g4 * 4) / QW, part = (g4 * 4 % QW) / 4;
+  reinterpret_cast<uint32_t *>(qtab)[(((size_t)grp * m_pad + j) * 256 + c) * (QW / 4) + part] = word;
+#ifdef GULON_FILTER_STAMPS
+  if (c == 0 && g_qt_stamps) {
+    unsigned long long *o = g_qt_stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = qs0; o[1] = qs1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = 0;
   }
+#endif
 }
 
 // ---- initial bounds from a strided sample of row blocks ---------------------------------------
-// One workgroup per W queries, their W-interleaved fp32 table in LDS, lane = row as in the
+// One workgroup per W queries (bound_tables below), their W-interleaved fp32 table in LDS, lane = row as in the
 // exact scan -- but no top-k lists in the loop: every lane only keeps the minimum exact distance
 // of the rows it saw (1024 disjoint groups of rows per workgroup).  Any K+1 group minima belong
 // to K+1 distinct rows, so the (K+1)-th smallest group minimum bounds the final (K+1)-th
@@ -164,19 +193,62 @@ __device__ inline float merge64_asc(float a, float b, int lane) {
   return x;
 }
 
+// the same two networks for 64-bit keys (the survivor pass orders (distance bits << 32) | row id)
+__device__ inline unsigned long long shfl_u64(unsigned long long x, int src) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)x, src), hi = (unsigned)__shfl((int)(unsigned)(x >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline unsigned long long shfl_xor_u64(unsigned long long x, int m) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)x, m), hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline unsigned long long sort64_u64(unsigned long long x, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const unsigned long long y = shfl_xor_u64(x, j);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      x = (lower == up) ? (x < y ? x : y) : (x < y ? y : x);
+    }
+  return x;
+}
+// a, b ascending: the 64 smallest of both, ascending
+__device__ inline unsigned long long merge64_u64(unsigned long long a, unsigned long long b, int lane) {
+  const unsigned long long br = shfl_u64(b, 63 - lane);
+  unsigned long long x = a < br ? a : br;      // bitonic sequence holding the 64 smallest
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) {
+    const unsigned long long y = shfl_xor_u64(x, j);
+    x = (lane & j) == 0 ? (x < y ? x : y) : (x < y ? y : x);
+  }
+  return x;
+}
+
 template <int W> struct FTab;
 template <> struct FTab<4> { using type = float4; };
 template <> struct FTab<2> { using type = float2; };
 template <> struct FTab<1> { using type = float; };
 
+// ---- the batch's first kernel: reset + Index.prepareQuery + sample scan in ONE launch ---------------------------
+// The three were separate launches (filter_reset, build_tables, bound_scan): 5 + 25 + 40 us on a 1.25 M-row shard, a
+// quarter of what the batch spends outside its main-stage kernel, and build_tables' 4096 workgroups take the whole chip
+// from another batch's filter kernel for their 20 us.  A sample-scan workgroup needs the fp32 tables of its W queries
+// in LDS anyway, so it BUILDS them there -- Index.prepareQuery's arithmetic (Index.scala:352-383: d = q - c,
+// sum += d * d, sequential, unfused), the same expression build_tables evaluates, hence the same bits -- writes them
+// out for the survivor pass, reduces the per-(query, quantizer) minima the quantisation needs, and clears its share of
+// the batch's counters on the way.  16 waves: wave w builds quantizers w, w + 16, ...; quantizer and
+// query are wave-uniform, so the query values arrive through scalar loads.
 template <int VEC, int W>
-__global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__restrict__ codes, int ng, int m_pad,
-                                                             const float *__restrict__ tables, int row_from,
-                                                             int row_until, int rb_begin, int e_count, RbMap mp, int B,
-                                                             int keff, float *__restrict__ tau0,
-                                                             float *__restrict__ fin_v, int *__restrict__ fin_i,
-                                                             float *__restrict__ bounds_out) {
-  constexpr int NW = FILTER_THREADS / 64;
+__global__ __launch_bounds__(BOUND_THREADS) void bound_tables(
+    const float *__restrict__ cents, const int *__restrict__ from, const int *__restrict__ sdim, int d, int m, int k,
+    const float *__restrict__ Q, float *__restrict__ tables, float *__restrict__ mins,
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ perm /* codes = the conflict-ordered copy: its row order */,
+    int ng, int m_pad, int row_from, int row_until, int rb_begin, int e_count,
+    RbMap mp, int B, int keff, float *__restrict__ tau0, float *__restrict__ fin_v, int *__restrict__ fin_i,
+    float *__restrict__ bounds_out, unsigned *__restrict__ gtau, int n_gtau, int *__restrict__ fb_tile, int n_fb,
+    int *__restrict__ sv_cnt, int n_cnt) {
+  constexpr int NW = BOUND_THREADS / 64;
   using Word = typename CodeWord<VEC>::type;
   using TV = typename FTab<W>::type;
   extern __shared__ uint4 qlds[];
@@ -184,12 +256,105 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qg = blockIdx.x;
-  {
-    const int nent = m_pad * 256;
-    const TV *src = reinterpret_cast<const TV *>(tables) + (size_t)qg * nent;
-    for (int e = tid; e < nent; e += FILTER_THREADS) lds[e] = src[e];
+#ifdef GULON_FILTER_STAMPS
+  unsigned long long bt0 = __builtin_amdgcn_s_memrealtime(), bt1 = 0, bt2 = 0, bx[4] = {0, 0, 0, 0};
+#endif
+  // (1) this batch's counters: pruning thresholds of the fallback scan, tile flags, survivor sub-queue fill levels
+  for (int t = qg * BOUND_THREADS + tid; t < max(n_gtau, max(n_fb, n_cnt)); t += gridDim.x * BOUND_THREADS) {
+    if (t < n_gtau) gtau[t] = 0x7F800000u;   // +inf
+    if (t < n_fb) fb_tile[t] = 0;
+    if (t < n_cnt) sv_cnt[t] = 0;
   }
+  if (qg * W >= B) return;                    // a padding group of the last query tile: no table, no bound
+  // (2) tables of queries qg*W .. +W-1, W-interleaved: entry (j, c) at lds[j * 256 + c].  Wave w owns quantizers
+  // w, w + 16, ...: sub-vector bounds and query values are wave-uniform, lane l evaluates centroids l, l + 64,
+  // l + 128, l + 192 one after the other, and the table minimum of a (query, quantizer) pair is a reduction inside the
+  // wave.  The loops are ROLLED on purpose: every wave runs through this code once per batch, out of a cold instruction
+  // cache -- unrolled (6.5 KiB) the section took 17.8 us of which the arithmetic is < 1 us (per-phase stamps); what
+  // such straight-line code costs is its size.
+  for (int j = wave; j < m_pad; j += NW) {
+    int fr = 0, s = 0;
+    if (j < m) { fr = from[j]; s = sdim[j]; }
+#ifdef GULON_FILTER_STAMPS
+    asm volatile("" :: "s"(fr), "s"(s));
+    if (j == wave) bx[0] = __builtin_amdgcn_s_memrealtime();     // sub-vector bounds arrived
+#endif
+    const float *cc = cents + (size_t)k * fr;
+    float mnu[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) mnu[u] = INFINITY;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+      const int c = lane + 64 * i;
+      float acc[W];
+#pragma unroll
+      for (int u = 0; u < W; u++) acc[u] = 0.f;
+#pragma unroll 1
+      for (int t0 = 0; t0 < s; t0 += 8) {
+        // eight dimensions per step.  The query values: lane 8 u + e loads component t0 + e of query u (one vector
+        // load; 32 guarded scalar loads took eight memory round trips), every lane then reads them with v_readlane.
+        // Dimensions beyond s contribute (0 - 0)^2 = +0 to a sum that is >= +0 or NaN: no change.
+        float qreg = 0.f;
+        {
+          const int lu = lane >> 3, le = lane & 7;
+          if (lu < W && t0 + le < s && qg * W + lu < B) qreg = Q[(size_t)(qg * W + lu) * d + fr + t0 + le];
+        }
+        // the centroid's eight components: two 16-byte loads where all eight exist (dword-aligned: s is arbitrary).
+        // Eight dword loads per lane, 32 bytes apart from lane to lane, touched every cache line eight times over and
+        // made this loop L1-bound: 3 us per centroid group (per-phase stamps)
+        float cv[8];
+        if (t0 + 8 <= s) {
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+          f32x4u lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+          if (c < k) {
+            const f32x4u *row = reinterpret_cast<const f32x4u *>(cc + (size_t)c * s + t0);
+            lo = row[0]; hi = row[1];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) { cv[e] = lo[e]; cv[4 + e] = hi[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) cv[e] = (t0 + e < s && c < k) ? cc[(size_t)c * s + t0 + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+#pragma unroll
+          for (int u = 0; u < W; u++) {
+            const float dd = readlane_f(qreg, 8 * u + e) - cv[e];
+            acc[u] += dd * dd;
+          }
+        }
+      }
+#ifdef GULON_FILTER_STAMPS
+      asm volatile("" :: "v"(acc[0]));
+      if (j == wave && i == 0) bx[1] = __builtin_amdgcn_s_memrealtime();   // first centroid group evaluated
+      if (j == wave && i == 3) bx[2] = __builtin_amdgcn_s_memrealtime();   // last centroid group evaluated
+#endif
+      TV tv;
+#pragma unroll
+      for (int u = 0; u < W; u++) {
+        if (!(c < k && qg * W + u < B)) acc[u] = 0.f;         // entries beyond k / of padding queries: zero
+        reinterpret_cast<float *>(&tv)[u] = acc[u];
+        if (c < k && acc[u] == acc[u]) mnu[u] = fminf(mnu[u], acc[u]);   // NaN entries are ignored
+      }
+      lds[j * 256 + c] = tv;       // (to LDS only: see the copy-out below)
+    }
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      float x = mnu[u];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+      if (lane == 0) mins[(size_t)(qg * W + u) * m_pad + j] = x;
+    }
+  }
+#ifdef GULON_FILTER_STAMPS
+  bx[3] = __builtin_amdgcn_s_memrealtime();                      // this wave's quantizers done (before the barrier)
+#endif
   __syncthreads();
+#ifdef GULON_FILTER_STAMPS
+  bt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // (3) the sample scan (see above): lane = row, every lane keeps the minimum exact distance it saw
   const Word *cw = reinterpret_cast<const Word *>(codes);
   int mp_p = wave / mp.width, mp_r = wave - mp_p * mp.width;
   auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
@@ -199,6 +364,13 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
   for (int u = 0; u < W; u++) mn[u] = INFINITY;
   Word w_first{};
   if (wave < e_count) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+  // The tables leave for global memory (the survivor pass and the quantisation read them) only now, in one burst
+  // BEHIND the first code-word request.  vmcnt counts loads and stores together, in order: with the store of a
+  // centroid group inside the build loop, the next group's loads waited for that store to be acknowledged (~3 us
+  // each, per-phase stamps: first group after 2.7 us, fourth after 11.5); a wait for the code word requested before
+  // the burst leaves the stores in flight.
+  for (int e = tid; e < m_pad * 256; e += BOUND_THREADS)
+    reinterpret_cast<TV *>(tables)[(size_t)qg * m_pad * 256 + e] = lds[e];
   for (int e = wave; e < e_count; e += NW) {
     const int rb = block_of(mp_p, mp_r);
     advance(mp_p, mp_r);
@@ -221,20 +393,35 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
       }
       w = wn;
     }
-    const int row = rb * 64 + lane;
-    if (row >= row_from && row < row_until) {
+    // which row a lane holds only matters in a block the range cuts (the conflict-ordered copy deals a block's rows to
+    // the lanes by `perm`; the sample only needs distances of DISTINCT rows of the range)
+    bool valid = true;
+    if (rb * 64 < row_from || rb * 64 + 64 > row_until) {
+      const int row = rb * 64 + (perm ? (int)perm[(size_t)rb * 64 + lane] : lane);
+      valid = row >= row_from && row < row_until;
+    }
+    if (valid) {
 #pragma unroll
       for (int u = 0; u < W; u++) mn[u] = fminf(mn[u], acc[u]);   // NaN distances are ignored
     }
   }
   __syncthreads();                     // the table is dead: reuse LDS for the per-wave sorted minima
+#ifdef GULON_FILTER_STAMPS
+  bt2 = __builtin_amdgcn_s_memrealtime();
+#endif
   float *sv = reinterpret_cast<float *>(qlds);
 #pragma unroll
-  for (int u = 0; u < W; u++) sv[(u * NW + wave) * 64 + lane] = sort64_asc(mn[u], lane);
+  for (int u = 0; u < W; u++) sv[(u * NW + wave) * 64 + lane] = mn[u];
+#pragma unroll 1                       // (one copy of the sorting network, not W: code size again)
+  for (int u = 0; u < W; u++) {
+    float *slot = sv + (u * NW + wave) * 64 + lane;
+    *slot = sort64_asc(*slot, lane);
+  }
   __syncthreads();
   if (wave < W) {
     const int u = wave, q = qg * W + u;
     float best = sv[(u * NW) * 64 + lane];
+#pragma unroll 1
     for (int w2 = 1; w2 < NW; w2++) best = merge64_asc(best, sv[(u * NW + w2) * 64 + lane], lane);
     if (q < B) {
       if (lane == keff - 1) tau0[q] = best;          // +inf when fewer than K+1 groups saw a row
@@ -242,6 +429,13 @@ __global__ __launch_bounds__(FILTER_THREADS) void bound_scan(const uint8_t *__re
       if (bounds_out && lane < keff) bounds_out[(size_t)q * keff + lane] = best;   // for the other shards
     }
   }
+#ifdef GULON_FILTER_STAMPS
+  if (tid == 0 && g_bt_stamps) {
+    unsigned long long *o = g_bt_stamps + 8 * (size_t)qg;
+    o[0] = bt0; o[1] = bt1; o[2] = bt2; o[3] = __builtin_amdgcn_s_memrealtime();
+    o[4] = bx[0]; o[5] = bx[1]; o[6] = bx[2]; o[7] = bx[3];
+  }
+#endif
 }
 
 // ---- bounds shared across shards: tau0[q] = the keff-th smallest of the union of `lists` ascending
@@ -283,6 +477,19 @@ __global__ __launch_bounds__(256) void shared_tau(const float *__restrict__ all 
 // ---- the filter: lane = row, 16*NQG queries per workgroup, NADD entries summed per byte -------
 // MAIN only tags the instantiation used for the last (large) stage, so that profilers list it apart
 // from the short first stage.
+#ifdef GULON_FILTER_STAMPS
+__global__ void dummy_kernel(const int *p) { if (p == nullptr) __builtin_trap(); }
+// experiment (timing only, results are stale): GULON_SKIP = 1 bound_tables | 2 qt_quantize | 4 survivors | 8 fallback + merges | 16 main stage
+static std::atomic<int> skip_calls{0};   // batches seen; the mask applies from batch GULON_SKIP_AFTER on (default 16)
+static int skip_mask() {
+  static const int m = getenv("GULON_SKIP") ? atoi(getenv("GULON_SKIP")) : 0;
+  static const int after = getenv("GULON_SKIP_AFTER") ? atoi(getenv("GULON_SKIP_AFTER")) : 16;
+  return skip_calls.load() > after ? m : 0;
+}
+#define GULON_SKIPPED(bit) (skip_mask() & (bit))
+#else
+#define GULON_SKIPPED(bit) false
+#endif
 template <int QW> struct QEntry;                     // QW queries (one byte each) per table entry
 template <> struct QEntry<16> { using type = uint4; };
 template <> struct QEntry<8> { using type = uint2; };
@@ -318,6 +525,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   const int tile = MAIN == 2 ? blockIdx.y : blockIdx.x, chunk = MAIN == 2 ? blockIdx.x : blockIdx.y;
   const int ntile = MAIN == 2 ? gridDim.y : gridDim.x;
   const int tab = m_pad * 256;   // entries per QW-query group
+#ifdef GULON_FILTER_STAMPS
+  unsigned long long stamp0 = 0, stamp1 = 0;
+  if constexpr (MAIN == 1) stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
   {   // every query of this tile already goes to the exact scan: nothing to do here
     const int q_lo = tile * NQG * QW, q_hi = min(B, q_lo + NQG * QW);
     bool any_live = false;
@@ -339,25 +550,63 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const int n16 = NQG * tab * QW / 16;   // 16-byte units (tab * QW is a multiple of 16)
     const uint4 *src = reinterpret_cast<const uint4 *>(qtab) + (size_t)tile * n16;
     for (int e = tid; e < n16; e += FILTER_THREADS) qlds_raw[e] = src[e];
+    if (tid == 0) *reinterpret_cast<int *>(qlds_raw + n16) = NW;   // run counter: the first NW runs are the waves' own
   }
   __syncthreads();
+#ifdef GULON_FILTER_STAMPS
+  if constexpr (MAIN == 1) stamp1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int e0 = chunk * e_per_chunk;
   const int e1 = min(e_limit, e0 + e_per_chunk);
   const Word *cw = reinterpret_cast<const Word *>(codes);
-  int mp_p = (e0 + wave) / mp.width, mp_r = (e0 + wave) - mp_p * mp.width;
   auto block_of = [&](int p, int r) { return rb_begin + p * mp.period + mp.lo + r; };
-  auto advance = [&](int &p, int &r) { r += NW; while (r >= mp.width) { r -= mp.width; p++; } };
-
+  // The chunk's row blocks are handed to the waves in RUNS through a counter in LDS, not dealt out in a fixed
+  // stride.  The LDS arbiter serves older waves first, so with a fixed share each the sixteen waves of a workgroup
+  // finished in four groups ~12 us apart (1.25 M-row shard, per-wave stamps: first wave 77 us, last 113 us), the
+  // workgroup's slot -- 16 wave slots and 64 KiB of LDS, which the next workgroup needs all at once -- stayed
+  // occupied by a thinning set of waves for a third of its life, and with both workgroups of a CU in that state the
+  // gather pipe ran dry (53 % of the chip's wave slots active at the troughs).  Drawing runs, fast waves take more
+  // blocks and all sixteen end within one run of each other.  The next run is drawn a whole run ahead (the result of
+  // the ds_add_rtn is read four row blocks later), so the code word of the next block -- the next of this run or
+  // the first of the next -- is still requested one block ahead.
+  constexpr int RUN = 4;
+  const int nruns = (e1 - e0 + RUN - 1) / RUN;
+  // block list position e -> (period p, offset r) = (e / width, e % width), once per run: multiply-high by
+  // floor((2^32 - 1) / width) + 1, exact for e < 2^32 / width
+  const uint32_t magic = mp.width > 1 ? 0xFFFFFFFFu / (uint32_t)mp.width + 1u : 0u;
+  auto locate = [&](int e, int &p, int &r) {
+    p = mp.width > 1 ? (int)__umulhi((uint32_t)e, magic) : e;
+    r = e - p * mp.width;
+  };
+  int *run_ctr = reinterpret_cast<int *>(qlds_raw + NQG * tab * QW / 16);   // = NW after the staging barrier
+  int run = wave, e = e0 + run * RUN, e_run_end = min(e1, e + RUN);
+  int mp_p = 0, mp_r = 0, grab_v = 0;
   Word w_first{};
-  if (e0 + wave < e1) w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
-  for (int e = e0 + wave; e < e1; e += NW) {
+  if (run < nruns) {
+    locate(e, mp_p, mp_r);
+    if (lane == 0) grab_v = atomicAdd(run_ctr, 1);
+    w_first = cw[((size_t)block_of(mp_p, mp_r) * ng) * 64 + lane];
+  }
+  while (run < nruns) {
     const int rb = block_of(mp_p, mp_r);
-    advance(mp_p, mp_r);
+    // the block after this one
+    int e_n = e + 1, p_n = mp_p, r_n = mp_r + 1, run_n = run, end_n = e_run_end;
+    if (r_n == mp.width) { r_n = 0; p_n++; }
+    if (e_n == e_run_end) {
+      run_n = __builtin_amdgcn_readfirstlane(grab_v);
+      if (run_n < nruns) {
+        e_n = e0 + run_n * RUN;
+        end_n = min(e1, e_n + RUN);
+        locate(e_n, p_n, r_n);
+        if (lane == 0) grab_v = atomicAdd(run_ctr, 1);
+      }
+    }
     const Word *p = cw + ((size_t)rb * ng) * 64 + lane;
     Word w = w_first;
     // (unconditional: the last iteration re-reads its own block -- a conditional load costs a copy of the word back)
-    w_first = cw[((size_t)(e + NW < e1 ? block_of(mp_p, mp_r) : rb) * ng) * 64 + lane];
+    w_first = cw[((size_t)(run_n < nruns ? block_of(p_n, r_n) : rb) * ng) * 64 + lane];
+    run = run_n; e = e_n; e_run_end = end_n; mp_p = p_n; mp_r = r_n;
 
     // acc[s][2*dd]   : 16-bit sums of queries 4dd (low half) and 4dd+2 (high half) of group s
     // acc[s][2*dd+1] : queries 4dd+1 and 4dd+3
@@ -481,29 +730,55 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
         }
     }
   }
+#ifdef GULON_FILTER_STAMPS
+  if constexpr (MAIN == 1) {   // per workgroup: [wave][start, staged, end] + [48] = (XCC_ID << 32) | HW_ID of wave 0
+    if (lane == 0 && g_filter_stamps) {
+      unsigned long long *o = g_filter_stamps + 52 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+      o[3 * wave] = stamp0; o[3 * wave + 1] = stamp1; o[3 * wave + 2] = __builtin_amdgcn_s_memrealtime();
+      if (wave == 0)
+        o[48] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+  }
+#endif
 }
 
 // ---- exact re-evaluation of the survivors; one workgroup (4 waves) per query -------------------
 // Wave 0 continues the query's running (K+1)-list; waves 1-3 collect into empty lists but only
-// what beats the running list's last entry; the four lists are merged through LDS at the end.
+// what beats the running list's last entry; the four sorted lists are merged through LDS at the end.
 constexpr int SV_WAVES = 4;
+// One workgroup = the W queries that share a W-interleaved fp32 table (scan.hip build_tables), SV_WAVES waves each:
+// the table (m_pad x 256 x W floats, 64 KiB at m = 16) is copied to LDS once, coalesced, and the sixteen look-ups of
+// every survivor are LDS gathers.  (One workgroup per query gathering from the table in global memory sent 17
+// scattered 64-byte requests per survivor through the texture path -- 4.4 M per batch -- which is also the path the
+// main-stage kernel of the next batch serves three of its sixteen look-ups from.)
 template <int VEC>
-__global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
+__global__ __launch_bounds__(64 * SV_WAVES * 4) void survivors_kernel(
     const uint8_t *__restrict__ codes, int ng, int m_pad, const float *__restrict__ tables, int W, int row_base,
     int *__restrict__ cnt, const int *__restrict__ queue, int cap, int B, int keff, float *__restrict__ fin_v,
     int *__restrict__ fin_i, int *__restrict__ fb_tile, int qt, int give_up /* survivors beyond which the filter is abandoned; 0: never */) {
   using Word = typename CodeWord<VEC>::type;
-  __shared__ float mv[(SV_WAVES - 1) * 64];
-  __shared__ int mi[(SV_WAVES - 1) * 64];
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  extern __shared__ uint4 sv_lds_raw[];
+  float *tlds = reinterpret_cast<float *>(sv_lds_raw);
+  __shared__ unsigned long long mk[4][(SV_WAVES - 1) * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qslot = wave_wg / SV_WAVES, wave = wave_wg - qslot * SV_WAVES;   // query of the group, wave of the query
+  const int q = blockIdx.x * W + qslot;
+  {
+    const int n16 = m_pad * 256 * W / 4;      // 16-byte units (W * 256 floats per quantizer: a multiple of 4)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(tables) + (size_t)blockIdx.x * n16;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(sv_lds_raw);
+    if (blockIdx.x * W < B)      // (read once: past the vector L1 the main-stage kernels gather from)
+      for (int e = tid; e < n16; e += 64 * SV_WAVES * W) dst[e] = __builtin_nontemporal_load(src + e);
+  }
   // sub-queue fill levels -> exclusive offsets of a flat numbering of this query's survivors
   int mine = lane < NSLOT ? cnt[q * NSLOT + lane] : 0;
-  __syncthreads();                                  // every wave has read the counters
+  __syncthreads();                                  // every wave has read the counters; the table is in LDS
   if (wave == 0 && lane < NSLOT) cnt[q * NSLOT + lane] = 0;
-  if (q >= B) return;
-  if (__ballot(mine > cap) != 0ull) {
-    if (tid == 0) fb_tile[q / qt] = 1;   // a sub-queue overflowed: the exact scan redoes this query tile
+  bool active = q < B;                              // (uniform per query; no early return: barriers below)
+  if (active && __ballot(mine > cap) != 0ull) {
+    if (wave == 0 && lane == 0) fb_tile[q / qt] = 1;   // a sub-queue overflowed: the exact scan redoes this query tile
     mine = min(mine, cap);
   }
   int incl = mine;
@@ -512,13 +787,14 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
     const int up = __shfl_up(incl, o);
     if (lane >= o) incl += up;
   }
-  const int n = readlane_i(incl, NSLOT - 1);
-  if (give_up > 0 && n > give_up) {
+  int n = readlane_i(incl, NSLOT - 1);
+  if (active && give_up > 0 && n > give_up) {
     // the bound lets too many rows through for this query (data without a tail of near rows):
     // filtering the rest would cost more than it saves -- its tile goes to the exact scan
-    if (tid == 0) fb_tile[q / qt] = 1;
-    return;
+    if (wave == 0 && lane == 0) fb_tile[q / qt] = 1;
+    active = false;
   }
+  if (!active) n = 0;
   int start[NSLOT];
 #pragma unroll
   for (int sl = 0; sl < NSLOT; sl++) start[sl] = readlane_i(incl - mine, sl);
@@ -532,16 +808,21 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
     return queue[((size_t)q * NSLOT + sl) * cap + (e - off)];
   };
 
-  // the running list, and its last entry as the admission bound of the helper waves
-  const float fv = lane < keff ? fin_v[(size_t)q * keff + lane] : INFINITY;
-  const int fi = lane < keff ? fin_i[(size_t)q * keff + lane] : INT_MAX;
-  const float bound_v = readlane_f(fv, keff - 1);
-  const int bound_i = readlane_i(fi, keff - 1);
-  WaveList wl;
-  wl.init();
-  if (wave == 0) { wl.v = fv; wl.i = fi; wl.tau = bound_v; wl.tau_i = bound_i; }
-  // W-interleaved fp32 tables: entry (j, c) of query q at ((q/W * m_pad + j) * 256 + c) * W + q%W
-  const float *tq = tables + (size_t)(q / W) * m_pad * 256 * W + q % W;
+  // The running list and every candidate as ONE 64-bit key, (distance bits << 32) | row id: distances are sums of
+  // squares (>= +0, or NaN, which sorts behind +inf and never enters), so the unsigned order of the key is the
+  // (distance, row id) order of the lists.  A wave sorts the 64 candidates of a step with a bitonic network and merges
+  // them into its running 64-list (the keff smallest are what counts): ~300 instructions per step.  (Feeding the
+  // candidates one by one into a sorted register list -- ballot, readlane, shift, ~40 instructions each, every
+  // candidate while a list fills up -- made this small kernel cost the batch 55 us next to another batch's main
+  // stage, which leaves no vector-ALU slots to spare.)
+  constexpr unsigned long long KEY_PAD = 0x7F8000007FFFFFFFull;      // (+inf, INT_MAX)
+  auto make_key = [](float v, int r) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)r; };
+  unsigned long long run = KEY_PAD;
+  if (active && lane < keff) run = make_key(fin_v[(size_t)q * keff + lane], fin_i[(size_t)q * keff + lane]);
+  const unsigned long long bound_key = shfl_u64(run, keff - 1);     // what a candidate has to beat
+  if (wave != 0) run = KEY_PAD;                                      // wave 0 continues the list, the others start empty
+  // W-interleaved fp32 tables (the group's copy in LDS): entry (j, c) of query q at (j * 256 + c) * W + q%W
+  const float *tq = tlds + qslot;
   const Word *cw = reinterpret_cast<const Word *>(codes);
   // survivors e = (SV_WAVES * it + wave) * 64 + lane; two-deep software pipeline: row ids two
   // batches ahead, first code word one batch ahead
@@ -550,6 +831,7 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
   int row_n = e0 < n ? entry(e0) : 0;
   Word w_n = cw[((size_t)(row_n >> 6) * ng) * 64 + (row_n & 63)];
   int row_nn = e0 + STEP < n ? entry(e0 + STEP) : 0;
+  unsigned long long admit = bound_key;                               // tightens to this wave's keff-th key
   for (int e = e0; e - lane < n; e += STEP) {
     const bool have = e < n;
     const int row = row_n;
@@ -566,30 +848,21 @@ __global__ __launch_bounds__(64 * SV_WAVES) void survivors_kernel(
 #pragma unroll
       for (int b = 0; b < VEC; b++) d += t[b];
     }
-    const int cr = row + row_base;
-    const bool in_bound = d < bound_v || (d == bound_v && cr < bound_i);
-    unsigned long long mk = __ballot(have && in_bound && wl.accepts(d, cr));
-    while (mk) {
-      const int l = __ffsll((long long)mk) - 1;
-      mk &= mk - 1;
-      const float v = readlane_f(d, l);
-      const int r = readlane_i(cr, l);
-      if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
-    }
+    unsigned long long key = make_key(d, row + row_base);
+    if (!(have && key < admit)) key = KEY_PAD;
+    if (__ballot(key != KEY_PAD) == 0ull) continue;
+    run = merge64_u64(run, sort64_u64(key, lane), lane);
+    admit = shfl_u64(run, keff - 1);
+    if (admit > bound_key) admit = bound_key;
   }
-  if (wave > 0) { mv[(wave - 1) * 64 + lane] = wl.v; mi[(wave - 1) * 64 + lane] = wl.i; }
+  if (wave > 0) mk[qslot][(wave - 1) * 64 + lane] = run;
   __syncthreads();
-  if (wave == 0) {
-    for (int w2 = 0; w2 < SV_WAVES - 1; w2++)
-      for (int e = 0; e < keff; e++) {
-        const float v = mv[w2 * 64 + e];
-        const int r = mi[w2 * 64 + e];
-        if (r == INT_MAX) break;      // sorted: the rest is padding
-        if (wl.accepts(v, r)) wl.insert(v, r, keff, lane);
-      }
+  if (wave == 0 && active) {
+#pragma unroll 1
+    for (int w2 = 0; w2 < SV_WAVES - 1; w2++) run = merge64_u64(run, mk[qslot][w2 * 64 + lane], lane);
     if (lane < keff) {
-      fin_v[(size_t)q * keff + lane] = wl.v;
-      fin_i[(size_t)q * keff + lane] = wl.i;
+      fin_v[(size_t)q * keff + lane] = __uint_as_float((unsigned)(run >> 32));
+      fin_i[(size_t)q * keff + lane] = (int)(unsigned)run;
     }
   }
 }
@@ -598,7 +871,7 @@ template <int QW, int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                      int from, int until, int cap, int stage, int B, hipStream_t st, int *fb, int qt) {
   const int W_fp32 = ix->w;
-  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW;
+  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW + 16;   // tables + the run counter
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
   constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
   // stage: 0 a short stage, 1 the main stage (a tag of its own for the profilers), 2 the tie replay's long level
@@ -621,10 +894,36 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
   }
   HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
+#ifdef GULON_FILTER_STAMPS
+  static unsigned long long *stamps_d = nullptr;
+  static size_t stamps_n = 0;
+  if (stage == 1 && getenv("GULON_FILTER_STAMPS")) {
+    const size_t need = (size_t)52 * ftiles * nchunks;
+    if (need > stamps_n) {
+      if (stamps_d) (void)hipFree(stamps_d);
+      HIP_CHECK(hipMalloc((void **)&stamps_d, need * 8));
+      stamps_n = need;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), &stamps_d, sizeof(stamps_d)));
+    }
+  }
+#endif
   hipLaunchKernelGGL(kern, stage == 2 ? dim3(nchunks, ftiles) : dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, codes, perm, ix->ng, ix->m_pad,
                      ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
                      fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B);
   HIP_CHECK(hipGetLastError());
+#ifdef GULON_FILTER_STAMPS
+  if (stage == 1 && stamps_d && getenv("GULON_FILTER_STAMPS")) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)52 * ftiles * nchunks);
+    HIP_CHECK(hipMemcpy(h.data(), stamps_d, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(getenv("GULON_FILTER_STAMPS"), "wb")) {
+      const int hdr[4] = {ftiles, nchunks, e_count, e_per_chunk};
+      fwrite(hdr, sizeof(int), 4, f);
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+  }
+#endif
 }
 
 // The filter kernel owns the LDS of every CU, so two of them (query batches in flight on
@@ -841,6 +1140,9 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
                       const SharedBounds *sb) {
   const ScanTuning &t = tuning_of(ix);
   const int phase = sb ? sb->phase : 0;
+#ifdef GULON_FILTER_STAMPS
+  if (phase != 2) skip_calls++;
+#endif
   const int keff = K + 1;
   const int W = ix->w;               // fp32 table interleave of the exact kernels
   const int QT = W * ix->nsub;
@@ -889,7 +1191,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
     const int most = std::max(1, ceil_div(target, tiles));        // launch-size cap
     const int fill = std::max(1, ceil_div(slots, tiles));         // every slot of the chip taken once
-    int nc = std::max(fill, std::min(most, e_count / 768));
+    static const int wg_blocks = getenv("GULON_FILTER_WG_BLOCKS") ? std::max(16, atoi(getenv("GULON_FILTER_WG_BLOCKS"))) : 768;   // experiment knob
+    int nc = std::max(fill, std::min(most, e_count / wg_blocks));
     if (nc > fill) nc -= nc % fill;                               // whole rounds
     nc = std::min(nc, std::max(1, e_count / NW));                 // at least one block per wave
     per = ceil_div(e_count, nc);
@@ -918,33 +1221,50 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   ix->tau0.ensure((size_t)Bp);
   ix->last_filter_tiles = ntiles;
   if (phase != 2) {
-    const int most = std::max(std::max(Bp, ntiles), Bq * NSLOT);
-    hipLaunchKernelGGL(filter_reset, dim3(ceil_div(most, 256)), dim3(256), 0, st, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,
-                       ix->sv_cnt.p, Bq * NSLOT);
-    HIP_CHECK(hipGetLastError());
-  }
-
-  // the table minima of the B real queries come out of the table build; the padding queries of the
-  // last 16-query quantisation group are dead and never read theirs
-  if (phase != 2) launch_build_tables(W, ix, dQ, B, Bp, ix->tables.p, st, nullptr, ix->qmins.p);
-  if (phase != 2) {   // bounds from a strided sample of about filter_sample rows; resets the running lists
+    // ONE launch: the batch's counters, Index.prepareQuery for all queries (with the table minima of the B real
+    // queries; the padding queries of the last 16-query quantisation group are dead and never read theirs) and the
+    // bounds from a strided sample of about filter_sample rows, which also resets the running lists
     int sblocks = std::max(NW, std::min(rb_total, ceil_div(srows, 64)));
     const RbMap smap{std::max(1, rb_total / sblocks), 0, 1};
     const int se = rbmap_count(rb_total, smap);
     const size_t lds_bytes = std::max((size_t)ix->m_pad * 256 * 4 * W, (size_t)W * NW * 64 * 4);
+    // the sample scan is a pure gather of 16-byte fp32 entries: it reads the conflict-ordered copy where there is one
+    const bool ordered = ix->fcodes.p && ix->ng == 1 && ix->vec == 16 && t.filter_order > 0;
+    const uint8_t *scodes = ordered ? ix->fcodes.p : ix->codes.p, *sperm = ordered ? ix->fperm.p : nullptr;
 #define BS(V, W_)                                                                                                   \
     {                                                                                                               \
-      auto kern = bound_scan<V, W_>;                                                                                \
+      auto kern = bound_tables<V, W_>;                                                                              \
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                   \
-      hipLaunchKernelGGL(kern, dim3(Bp / W_), dim3(FILTER_THREADS), lds_bytes, st, ix->codes.p, ix->ng, ix->m_pad,  \
-                         ix->tables.p, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p,           \
-                         ix->fin_i.p, phase == 1 ? sb->bounds_out : nullptr);                                       \
+      hipLaunchKernelGGL(kern, dim3(Bp / W_), dim3(BOUND_THREADS), lds_bytes, st, ix->cents.p, ix->from.p,          \
+                         ix->sdim.p, ix->d, ix->m, ix->k, dQ, ix->tables.p, ix->qmins.p, scodes, sperm, ix->ng,     \
+                         ix->m_pad, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p, ix->fin_i.p, \
+                         phase == 1 ? sb->bounds_out : nullptr, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,              \
+                         ix->sv_cnt.p, Bq * NSLOT);                                                                 \
     }
-    if (ix->vec == 16) { if (W == 4) BS(16, 4) else if (W == 2) BS(16, 2) else BS(16, 1) }
+#ifdef GULON_FILTER_STAMPS
+    static unsigned long long *bt_d = nullptr;
+    if (getenv("GULON_FILTER_STAMPS") && !bt_d) {
+      HIP_CHECK(hipMalloc((void **)&bt_d, 8 * 8 * 65536));
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_stamps), &bt_d, sizeof(bt_d)));
+    }
+#endif
+    if (GULON_SKIPPED(1)) {}
+    else if (ix->vec == 16) { if (W == 4) BS(16, 4) else if (W == 2) BS(16, 2) else BS(16, 1) }
     else               { if (W == 4) BS(4, 4) else if (W == 2) BS(4, 2) else BS(4, 1) }
 #undef BS
     HIP_CHECK(hipGetLastError());
+#ifdef GULON_FILTER_STAMPS
+    if (bt_d && Bp / W <= 65536) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h((size_t)8 * (Bp / W));
+      HIP_CHECK(hipMemcpy(h.data(), bt_d, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen((std::string(getenv("GULON_FILTER_STAMPS")) + ".bt").c_str(), "wb")) {
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    }
+#endif
   }
   if (phase == 1) return;     // the caller exchanges the bounds and comes back with phase 2
   if (phase == 2) {
@@ -958,11 +1278,30 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     if (en <= 0) continue;
     int nc = 1, per = 1;
     chunking(en, ftiles, t.filter_blocks, nc, per);
-    hipLaunchKernelGGL(qt_quantize, dim3(Bq / 16, ix->m_pad), dim3(256), 0, st, ix->tables.p, W, Bp, ix->m_pad, ix->k,
+#ifdef GULON_FILTER_STAMPS
+    static unsigned long long *qt_d = nullptr;
+    if (getenv("GULON_FILTER_STAMPS") && !qt_d) {
+      HIP_CHECK(hipMalloc((void **)&qt_d, 8 * 4 * 65536));
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_qt_stamps), &qt_d, sizeof(qt_d)));
+    }
+#endif
+    if (!GULON_SKIPPED(2))
+    hipLaunchKernelGGL(qt_quantize, dim3(Bq / 4, ix->m_pad), dim3(256), 0, st, ix->tables.p, W, Bp, ix->m_pad, ix->k,
                        B, ix->qmins.p, ix->fin_v.p, ix->fin_i.p, ix->tau0.p, keff, qmax, qw, ix->qtab.p,
                        ix->fb_tile.p, QT);
     HIP_CHECK(hipGetLastError());
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+#ifdef GULON_FILTER_STAMPS
+    if (qt_d && (Bq / 4) * ix->m_pad <= 65536) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h((size_t)4 * (Bq / 4) * ix->m_pad);
+      HIP_CHECK(hipMemcpy(h.data(), qt_d, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen((std::string(getenv("GULON_FILTER_STAMPS")) + ".qt").c_str(), "wb")) {
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    }
+#endif
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, lane_pending = nullptr;
     const bool main_stage = sidx == 2;
     // a first stage that keeps more than ~3 % of its (query, row) pairs means the bounds do not
     // separate anything for this query: give up on it before the main stage
@@ -979,10 +1318,14 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       const hipEvent_t lane_ev = filter_lane().of(dev, fresh);
       // only the main stage takes turns.  (Two host threads enqueueing at the same instant may both wait for the SAME
       // earlier launch and then share the chip once: the event orders launches for throughput, never for results.)
-      if (main_stage && !fresh) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
+      static const bool take_turns = !(getenv("GULON_FILTER_LANE") && atoi(getenv("GULON_FILTER_LANE")) == 0);   // experiment knob
+      if (main_stage && !fresh && take_turns) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
+      if (!(main_stage && GULON_SKIPPED(16)))
       launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage ? 1 : 0, B, st);
-      if (main_stage) HIP_CHECK(hipEventRecord(lane_ev, st));
+      static const int lane_after = getenv("GULON_LANE_AFTER_SURVIVORS") ? atoi(getenv("GULON_LANE_AFTER_SURVIVORS")) : 0;   // experiment knob
+      if (main_stage && !lane_after) HIP_CHECK(hipEventRecord(lane_ev, st));
+      lane_pending = main_stage && lane_after ? lane_ev : nullptr;
     }
     if (stats) {   // debugging aid (GULON_FILTER_STATS=1): synchronous survivor statistics
       HIP_CHECK(hipStreamSynchronize(st));
@@ -998,15 +1341,17 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       ix->events.emplace_back(ev0, ev1);
       ix->prof_rows += std::min<long long>((long long)en * 64, (long long)until - from);
     }
-    if (ix->vec == 16)
-      hipLaunchKernelGGL(survivors_kernel<16>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
-                         W, ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
-                         ix->fb_tile.p, QT, give_up);
-    else
-      hipLaunchKernelGGL(survivors_kernel<4>, dim3(Bq), dim3(64 * SV_WAVES), 0, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
-                         W, ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
-                         ix->fb_tile.p, QT, give_up);
+    {
+      const size_t sv_lds = (size_t)ix->m_pad * 256 * W * sizeof(float);
+      auto kern = ix->vec == 16 ? survivors_kernel<16> : survivors_kernel<4>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv_lds));
+      if (!GULON_SKIPPED(4))
+        hipLaunchKernelGGL(kern, dim3(Bq / W), dim3(64 * SV_WAVES * W), sv_lds, st, ix->codes.p, ix->ng, ix->m_pad, ix->tables.p,
+                           W, ix->row_base, ix->sv_cnt.p, ix->sv_queue.p, cap, B, keff, ix->fin_v.p, ix->fin_i.p,
+                           ix->fb_tile.p, QT, give_up);
+    }
     HIP_CHECK(hipGetLastError());
+    if (lane_pending) HIP_CHECK(hipEventRecord(lane_pending, st));   // the next batch's main stage starts behind this batch's survivor pass
   }
 
   // fallback (device-side decision): flagged query tiles are rescanned exactly over all rows
@@ -1023,12 +1368,20 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     if (*hint != 0) { *hint = 0; ix->fb_wide_left = 8; }
     const bool wide = ix->fb_wide_left > 0;
     if (wide) ix->fb_wide_left--;
+    if (!GULON_SKIPPED(8))
     launch_scan(ix, fb_tiles, cfb_n, rb_begin, rb_total, pfb, all, from, until, keff, st, nullptr, nullptr,
                 ix->fb_tile.p, true, wide ? fb_tiles : 8, ix->fb_hint_d);
   }
+  if (!GULON_SKIPPED(8))
   launch_merge_enabled(ix->part_v.p, ix->part_i.p, cfb_n, (long long)keff, (long long)cfb_n * keff, B, K, ix->fin_v.p,
                        ix->fin_i.p, ix->fb_tile.p, QT, st);
 
+#ifdef GULON_FILTER_STAMPS
+  {   // experiment: what does one more (empty) launch per batch cost while other batches are in flight?
+    static const int dummies = getenv("GULON_DUMMY_LAUNCHES") ? atoi(getenv("GULON_DUMMY_LAUNCHES")) : 0;
+    for (int i = 0; i < dummies; i++) hipLaunchKernelGGL(dummy_kernel, dim3(64), dim3(64), 0, st, ix->fb_tile.p);
+  }
+#endif
   if (stats) {
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<int> h((size_t)ntiles);
@@ -1079,7 +1432,7 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   HIP_CHECK(hipMemsetAsync(ix->sv_cnt.p, 0, sizeof(int) * (size_t)Fq * NSLOT, st));
   // tables of the flagged queries are [slot][m_pad][256]: "one query per entry" (W = 1) in qt_quantize's terms, read
   // through the order; queries beyond F (the padding of the last 16-query group) read no table
-  hipLaunchKernelGGL(qt_quantize, dim3(Fq / 16, ix->m_pad), dim3(256), 0, st, tables, 1, F, ix->m_pad, ix->k, F, mins,
+  hipLaunchKernelGGL(qt_quantize, dim3(Fq / 4, ix->m_pad), dim3(256), 0, st, tables, 1, F, ix->m_pad, ix->k, F, mins,
                      ix->rp_finv.p, ix->rp_fini.p, ix->rp_tau.p, 1, qmax, qw, ix->qtab.p, ix->rp_fb.p, 1, ix->rp_order.p);
   HIP_CHECK(hipGetLastError());
   const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw;

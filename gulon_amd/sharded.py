@@ -128,9 +128,16 @@ class HipEngine:
 class ShardedIndex:
     """One rank's view of the row-sharded flat index."""
 
-    def __init__(self, engine, n_total, rank=0, world=1, dist=None, rehearse=False):
+    def __init__(self, engine, n_total, rank=0, world=1, dist=None, rehearse=False, emulate_world=0):
         self.engine = engine
         self.n_total, self.rank, self.world, self.dist = n_total, rank, world, dist
+        # emulate_world = N > 1 (bench.py, GULON_BENCH_REHEARSE=N on a one-GPU box): this process does exactly what
+        # rank 0 of N does per batch -- its 1/N of the rows, N lists per exchange -- over a ONE-rank process group:
+        # every all-gather moves this rank's slot, the other N - 1 slots hold what the other ranks would have sent
+        # for the same queries (`prefill`, computed once from their shards)
+        self.emulate = emulate_world > 1
+        if self.emulate:
+            self.world = emulate_world
         # the multi-rank pipeline (partial lists -> all-gather -> merge -> replay exchange); `rehearse`
         # runs it with a one-rank process group as well, so that the RCCL path can be exercised and
         # timed on a one-GPU box (bench.py: GULON_BENCH_REHEARSE=1)
@@ -140,7 +147,7 @@ class ShardedIndex:
         import os
         self.share_bounds = (self.collective and hasattr(engine, "scan_bounds")
                              and os.environ.get("GULON_SHARED_BOUNDS", "1") != "0")
-        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self.lo, self.hi = shard_bounds(n_total, self.world, rank)
         self._bufs = {}
         # RCCL gathers device tensors directly; a gloo group (CPU rehearsal of the multi-rank path
         # with the real HIP engine) needs the lists staged through the host
@@ -169,6 +176,10 @@ class ShardedIndex:
         return self._bufs[key]
 
     def _all_gather(self, out, inp):
+        if self.emulate:
+            # one-rank group: the collective writes slot 0; slots 1 .. N-1 were filled by prefill()
+            self.dist.all_gather_into_tensor(out.view(-1)[:inp.numel()].view(inp.shape), inp)
+            return
         if self.host_staged:
             # rehearsal path (gloo has no device collectives): same layout, staged through the host
             hi, ho = inp.cpu(), out.cpu()
@@ -180,32 +191,73 @@ class ShardedIndex:
     def batch_query_dev(self, q, b, k):
         """Enqueue one batch; returns the (device) output tensors idx, dist, count, flags."""
         u = self._buffers(b, k)
+        tick = self._tick
         if not self.collective:
             self.engine.query_final(q, b, k, u["oi"], u["od"], u["oc"], u["of"])
         else:
             pv, pi = self.engine.views(u["pk"], b)
             large_k = k > N.MAX_K      # beyond a wavefront list: peeled partial lists, long merge, (distance, row) ties
             if self.share_bounds and not large_k:
-                self.engine.scan_bounds(q, b, k, u["bd"])
-                self._all_gather(u["abd"], u["bd"])
-                self.engine.scan_partial_bounded(q, b, k, u["abd"], self.world, pv, pi)
+                self.engine.scan_bounds(q, b, k, u["bd"]); tick("scan_bounds")
+                self._all_gather(u["abd"], u["bd"]); tick("all_gather bounds")
+                self.engine.scan_partial_bounded(q, b, k, u["abd"], self.world, pv, pi); tick("scan_partial_bounded")
             else:
-                self.engine.scan_partial(q, b, k, pv, pi)
-            self._all_gather(u["apk"], u["pk"])
-            self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"])
+                self.engine.scan_partial(q, b, k, pv, pi); tick("scan_partial")
+            self._all_gather(u["apk"], u["pk"]); tick("all_gather lists")
+            self.engine.merge(u["apk"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"]); tick("merge")
             if "rp" in u and not large_k:
                 # queries with exact distance ties: every shard contributes the rows that may insert into
                 # the reference's heap, the union is replayed identically on every rank (TopKHeap.scala:57-79).
                 # This first round (replay_first queries) is unconditional -- no host synchronisation;
                 # complete() looks at the batch's flag count afterwards and runs further rounds if needed.
                 e = self.engine
-                e.replay_collect(q, b, k, u["of"], u["rp"], 0, e.replay_first)
-                self._all_gather(u["arp"], u["rp"])
-                e.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"], e.replay_first)
+                e.replay_collect(q, b, k, u["of"], u["rp"], 0, e.replay_first); tick("replay_collect")
+                self._all_gather(u["arp"], u["rp"]); tick("all_gather candidates")
+                e.replay_apply(u["arp"], self.world, b, k, u["oi"], u["od"], u["oc"], u["of"], e.replay_first); tick("replay_apply")
                 self._pending = (q, b, k)
             if hasattr(self.engine, "nan_fix"):
-                self.engine.nan_fix(q, b, k, self.n_total, u["oi"], u["od"], u["oc"], u["of"])
+                self.engine.nan_fix(q, b, k, self.n_total, u["oi"], u["od"], u["oc"], u["of"]); tick("nan_fix")
         return u["oi"], u["od"], u["oc"], u["of"]
+
+    # host-side cost of a step, call by call (GULON_HOST_PROFILE=1; bench.py prints the table to stderr)
+    host_profile = None
+
+    def _tick(self, name):
+        hp = ShardedIndex.host_profile
+        if hp is not None:
+            import time
+            now = time.perf_counter()
+            hp[name] = hp.get(name, 0.0) + now - hp["_last"]
+            hp["_last"] = now
+
+    def prefill(self, q, b, k, other_engines):
+        """Emulation of rank 0 of N: fill slots 1 .. N-1 of every gather buffer with what ranks 1 .. N-1 send for the
+        batch (q, b, k) -- their sample bounds, their partial lists against the shared bound, their tie-replay
+        candidates.  other_engines[r - 1] = an engine over rank r's rows (row_base = its first row)."""
+        assert self.emulate and self.share_bounds and len(other_engines) == self.world - 1
+        u, W = self._buffers(b, k), self.world
+        engs = [self.engine] + list(other_engines)
+        abd = u["abd"].view(W, b, k + 1)
+        for r, e in enumerate(engs):
+            e.scan_bounds(q, b, k, abd[r])       # (left pending; the next call on the handle drops it)
+        apk = u["apk"].view(W, 2 * b, k + 1)
+        for r, e in enumerate(engs):
+            e.scan_bounds(q, b, k, u["bd"])
+            pv, pi = e.views(apk[r], b)
+            e.scan_partial_bounded(q, b, k, u["abd"], W, pv, pi)
+        self.engine.merge(u["apk"], W, b, k, u["oi"], u["od"], u["oc"], u["of"])
+        if "rp" in u:
+            arp = u["arp"].view(W, -1)
+            for r, e in enumerate(engs):
+                e.replay_collect(q, b, k, u["of"], arp[r], 0, self.engine.replay_first)
+        self.engine.torch.cuda.synchronize()
+
+    def copy_prefill(self, other, b, k):
+        """The same slots 1 .. N-1 for another workspace of the same shard (one per batch in flight)."""
+        u, v = self._buffers(b, k), other._buffers(b, k)
+        for key in ("abd", "apk", "arp"):
+            if key in u:
+                u[key].copy_(v[key])
 
     def complete(self):
         """Finish the batch enqueued last: when more queries were tie-flagged than the first replay round
@@ -213,12 +265,19 @@ class ShardedIndex:
         been replayed.  Waits for the batch (reads its flag count); every rank sees the same count, so all
         ranks run the same number of rounds.  Returns the number of extra rounds."""
         pend, self._pending = getattr(self, "_pending", None), None
+        if ShardedIndex.host_profile is not None:
+            import time
+            ShardedIndex.host_profile["_last"] = time.perf_counter()
         if pend is None:
             return 0
         q, b, k = pend
         u, e = self._buffers(b, k), self.engine
         total, skip, rounds = e.replay_total(u["rp"]), e.replay_first, 0
+        self._tick("complete: wait for the flag count of this slot's previous batch")
         self.last_flagged = total
+        if self.emulate and total > skip:
+            raise RuntimeError(f"rank emulation holds the other ranks' candidates for {skip} tie-flagged queries only; "
+                               f"this batch has {total}")
         if total > skip:
             words = e.replay_words(e.replay_more)
             if "rp2" not in u:

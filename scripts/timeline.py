@@ -7,7 +7,7 @@ import sys
 f = (glob.glob(sys.argv[1] + '/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'build_tables<true, 4>' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if ('build_tables<true, 4>' in r['Kernel_Name'] or 'bound_tables<' in r['Kernel_Name'])]
 i0, i1 = idx[-2], idx[-1]
 t0 = int(rows[i0]['Start_Timestamp'])
 prev = t0
