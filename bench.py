@@ -27,6 +27,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def kernel_source_sha16(kernel_name):
+    """Identity of the kernel a committed counter pass describes: sha256 over the sources it is built from."""
+    import hashlib
+    files = {"filter_kernel": ["filter.hip", "conflict_order.hip", "scan.hpp", "common.hpp"],
+             "scan_kernel": ["scan.hip", "scan.hpp", "common.hpp"]}[kernel_name]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "gulon_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def run_steps(torch, shardeds, streams, Q, B, K, steps):
     """`steps` timed batches round-robin over the workspaces (after one untimed round); ms per step + last outputs."""
     nfl = len(shardeds)
@@ -368,11 +379,18 @@ def main():
     # physical side of the same kernel: HBM bytes and LDS / VALU counters per launch come from the committed
     # rocprofv3 --pmc passes of this very command (profiles/scan_traffic.json names the csv they were read from);
     # the duration they are divided by is the one measured live above
-    traffic, physical = None, None
+    traffic, physical, physical_note = None, None, None
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf)).get(f"{kernel_name}_n{nloc}_m{m}_B{B}")
+            if rec is None:
+                physical_note = f"no counter pass committed for {kernel_name} at n={nloc}, m={m}, B={B}"
+            elif rec.get("source_sha16") != kernel_source_sha16(kernel_name):
+                # counters of another version of the kernel say nothing about this one
+                physical_note = (f"stale: the committed counters ({rec.get('source')}) were taken from kernel sources "
+                                 f"{rec.get('source_sha16')}, this build is {kernel_source_sha16(kernel_name)}")
+                rec = None
             traffic = rec["hbm_bytes_per_launch"] if rec else None
             if rec and scan_ms > 0:
                 hbm_gbs = traffic / (scan_ms * 1e-3) / 1e9
@@ -417,7 +435,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                      "kernel_ms": scan_ms, "launches_per_step": launches.value / max(args.steps, 1),
                      "algorithmic_bytes_per_launch": alg_bytes, "basis": "algorithmic bytes, not DRAM traffic",
-                     "physical": physical},
+                     "physical": physical, "physical_note": physical_note},
         "build_seconds": build_s,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
     }
@@ -461,12 +479,22 @@ def main():
                         break
                 oi, od = np.concatenate(ois), np.concatenate(ods)
                 same_d = bool(np.array_equal(od.view(np.uint32), res_dist[:n_q].view(np.uint32)))
-                same_i = bool(all(res_flg[q] != 0 or np.array_equal(oi[q], res_idx[q]) for q in range(n_q)))
+                # ids are claimed exact for unflagged queries AND for replayed ones (flag 4); a flagged query
+                # that was not replayed may differ only inside the tie group of its last distance
+                def ids_ok(q):
+                    if res_flg[q] == 0 or (res_flg[q] & 4):
+                        return np.array_equal(oi[q], res_idx[q])
+                    inner = od[q] < od[q][-1]
+                    return set(oi[q][inner].tolist()) == set(res_idx[q][inner].tolist())
+                same_i = bool(all(ids_ok(q) for q in range(n_q)))
                 result["cpu_baseline"] = {
                     "value": n_q / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
                     "sample": f"first {n_q} of the {B} queries over all {n} rows, single thread, "
                               f"4096-row blocks (Index.scala:424); C restatement of Gulon's JVM algorithm"}
-                result["parity_vs_oracle"] = {"queries": n_q, "distances_bit_exact": same_d, "ids_equal": same_i}
+                result["parity_vs_oracle"] = {
+                    "queries": n_q, "distances_bit_exact": same_d, "ids_equal": same_i,
+                    "tie_flagged": int((res_flg[:n_q] != 0).sum()), "replayed": int(((res_flg[:n_q] & 4) != 0).sum()),
+                    "flagged_not_replayed": int(((res_flg[:n_q] != 0) & ((res_flg[:n_q] & 4) == 0)).sum())}
                 # the same restatement with the queries striped over the host cores -- one index.query per
                 # task, as Tests.recallOf runs them (Tests.scala:22-29, parTraverse); a second, bounded sample
                 cores = min(len(os.sched_getaffinity(0)), 16)

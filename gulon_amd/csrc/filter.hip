@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void shared_tau(const float *__restrict__ all 
 // from the short first stage.
 #ifdef GULON_FILTER_STAMPS
 __global__ void dummy_kernel(const int *p) { if (p == nullptr) __builtin_trap(); }
-// experiment (timing only, results are stale): GULON_SKIP = 1 bound_tables | 2 qt_quantize | 4 survivors | 8 fallback + merges | 16 main stage
+// experiment (timing only, results are stale): GULON_SKIP = 1 bound_tables | 2 qt_quantize | 4 survivors | 8 fallback + merges | 16 main stage | 32 short first stage
 static std::atomic<int> skip_calls{0};   // batches seen; the mask applies from batch GULON_SKIP_AFTER on (default 16)
 static int skip_mask() {
   static const int m = getenv("GULON_SKIP") ? atoi(getenv("GULON_SKIP")) : 0;
@@ -871,7 +871,10 @@ template <int QW, int NQG, int VEC, int NADD>
 void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int e_count, int e_per_chunk, RbMap mp,
                      int from, int until, int cap, int stage, int B, hipStream_t st, int *fb, int qt) {
   const int W_fp32 = ix->w;
-  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW + 16;   // tables + the run counter
+  // (GULON_FILTER_LDS_PAD: experiment knob -- bytes of LDS a main-stage workgroup claims on top of its tables, so
+  // that fewer of them fit a CU)
+  static const size_t lds_pad = getenv("GULON_FILTER_LDS_PAD") ? (size_t)atoi(getenv("GULON_FILTER_LDS_PAD")) : 0;
+  const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW + 16 + (stage == 1 ? lds_pad : 0);   // tables + the run counter
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
   constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
   // stage: 0 a short stage, 1 the main stage (a tag of its own for the profilers), 2 the tie replay's long level
@@ -1185,7 +1188,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   // 64-128 KiB of tables once (268 MB through L2 for 4096 workgroups), so it should get >= 768 row blocks
   // (48 per wave) where the range allows; the launch is a whole number of rounds of what the chip holds
   // at once (CUs x resident workgroups) where that is possible
-  const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw;
+  static const size_t lds_pad = getenv("GULON_FILTER_LDS_PAD") ? (size_t)atoi(getenv("GULON_FILTER_LDS_PAD")) : 0;
+  const size_t filter_lds = (size_t)nqg * ix->m_pad * 256 * qw + lds_pad;
   const int resident = std::max(1, std::min(2048 / FILTER_THREADS, (int)(160 * 1024 / filter_lds)));
   const int slots = device_cus() * resident;
   auto chunking = [&](int e_count, int tiles, int target, int &nchunks, int &per) {
@@ -1319,9 +1323,13 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       // only the main stage takes turns.  (Two host threads enqueueing at the same instant may both wait for the SAME
       // earlier launch and then share the chip once: the event orders launches for throughput, never for results.)
       static const bool take_turns = !(getenv("GULON_FILTER_LANE") && atoi(getenv("GULON_FILTER_LANE")) == 0);   // experiment knob
-      if (main_stage && !fresh && take_turns) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
+      // (ranges below ~2 M rows -- a shard of an 8-GPU index -- do better without the turn-taking: 0.413 against 0.430 ms
+      // per batch at 1.25 M rows, three batches in flight; 10 M rows: 2.36 against 2.38, within the noise, and the
+      // kernel durations the bench reports stay those of one kernel at a time)
+      const bool turns = take_turns && (long long)rb_total * 64 >= (2ll << 20);
+      if (main_stage && !fresh && turns) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
-      if (!(main_stage && GULON_SKIPPED(16)))
+      if (!(main_stage && GULON_SKIPPED(16)) && !(!main_stage && GULON_SKIPPED(32)))
       launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage ? 1 : 0, B, st);
       static const int lane_after = getenv("GULON_LANE_AFTER_SURVIVORS") ? atoi(getenv("GULON_LANE_AFTER_SURVIVORS")) : 0;   // experiment knob
       if (main_stage && !lane_after) HIP_CHECK(hipEventRecord(lane_ev, st));

@@ -117,10 +117,11 @@ struct gulon_sharded_index {
     for (auto &dv : devs) {
       (void)hipSetDevice(dv.device);
       if (dv.st) (void)hipStreamSynchronize(dv.st);
-      for (auto &s : dv.slots) {
-        if (!s.ix) continue;
-        if (s.padding) delete s.ix; else gulon_index_destroy(s.ix);
-      }
+      // padding slots borrow the buffers of the device's owner slot: they go first
+      for (auto &s : dv.slots)
+        if (s.ix && s.padding) { delete s.ix; s.ix = nullptr; }
+      for (auto &s : dv.slots)
+        if (s.ix) gulon_index_destroy(s.ix);
       dv.slots.clear();
       if (dv.comm && rccl().CommDestroy) (void)rccl().CommDestroy(dv.comm);
       dv.q.release(); dv.bd_send.release(); dv.bd_all.release(); dv.od.release();
@@ -137,12 +138,21 @@ namespace {
 template <class Bufs>
 void all_gather(gulon_sharded_index *sx, Bufs bufs, size_t count, ncclDataType_t ty) {
   Rccl &r = rccl();
+  // the group is closed on EVERY path: a failure between GroupStart and GroupEnd that left it open would nest
+  // every later collective of this thread inside it -- they would never launch
+  struct Group {
+    Rccl &r;
+    bool open = false;
+    ~Group() { if (open) (void)r.GroupEnd(); }
+  } group{r};
   NCCL_CHECK(r.GroupStart());
+  group.open = true;
   for (auto &dv : sx->devs) {
     HIP_CHECK(hipSetDevice(dv.device));
     std::pair<const void *, void *> sr = bufs(dv);
     NCCL_CHECK(r.AllGather(sr.first, sr.second, count, ty, dv.comm, dv.st));
   }
+  group.open = false;
   NCCL_CHECK(r.GroupEnd());
 }
 

@@ -4,8 +4,13 @@
  * On a box with a JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
  *       gulon_jni.c -L../../gulon_amd/lib -lgulon_hip -o libgulon_jni.so
- * Java names: net.tixxit.gulon.hip.Native (see ../scala/.../Native.scala); tests/test_integration_docs.py keeps the
- * three lists -- this file, Native.scala and the table of INTEGRATION.md -- identical.
+ * Java names: the natives are `@native def`s of the Scala `object net.tixxit.gulon.hip.Native`
+ * (../scala/.../Native.scala).  scalac puts a native method of an object on its MODULE CLASS `Native$` -- the static
+ * forwarders of `Native` call `Native$.MODULE$.f(...)` -- so the JVM resolves
+ *   Java_net_tixxit_gulon_hip_Native_00024_<method>(JNIEnv *, jobject self, ...)
+ * (`$` is mangled as `_00024`; an instance method: the receiver is the module instance, a jobject, not a jclass).
+ * tests/test_integration_docs.py keeps the three lists -- this file, Native.scala and the table of INTEGRATION.md --
+ * identical, and checks every native's parameter count and JNI types against its Scala signature.
  * Error mapping (include/gulon_hip.h): INVALID_ARGUMENT -> IllegalArgumentException (the reference's `require`),
  * ILLEGAL_STATE -> IllegalStateException, UNSUPPORTED -> UnsupportedOperationException, OOM -> OutOfMemoryError,
  * else RuntimeException.  A null array / buffer from the JVM side throws IllegalArgumentException before the
@@ -16,7 +21,7 @@
 #include <stdlib.h>
 #include "gulon_hip.h"
 
-#define NAT(ret, name) JNIEXPORT ret JNICALL Java_net_tixxit_gulon_hip_Native_##name
+#define NAT(ret, name) JNIEXPORT ret JNICALL Java_net_tixxit_gulon_hip_Native_00024_##name
 
 static void throw_named(JNIEnv *env, const char *cls, const char *msg) {
   jclass c = (*env)->FindClass(env, cls);
@@ -59,18 +64,18 @@ static void unpin(JNIEnv *env, pin_t *t) {
 #define DS(h) ((gulon_dataset *)(intptr_t)(h))
 
 /* ---- Matrix (Matrix.scala:3): Matrix.data flattened by the Scala side into one direct FloatBuffer ---- */
-NAT(jlong, datasetCreate)(JNIEnv *env, jclass c, jobject buf, jint n, jint d) {
+NAT(jlong, datasetCreate)(JNIEnv *env, jobject self, jobject buf, jint n, jint d) {
   gulon_dataset *ds = NULL;
   const float *x = buf ? (const float *)(*env)->GetDirectBufferAddress(env, buf) : NULL;
   if (!x) { throw_named(env, "java/lang/IllegalArgumentException", "expected a direct FloatBuffer"); return 0; }
   if (throw_status(env, gulon_dataset_create(x, n, d, &ds))) return 0;
   return (jlong)(intptr_t)ds;
 }
-NAT(void, datasetDestroy)(JNIEnv *env, jclass c, jlong h) { gulon_dataset_destroy(DS(h)); }
+NAT(void, datasetDestroy)(JNIEnv *env, jobject self, jlong h) { gulon_dataset_destroy(DS(h)); }
 
 /* ---- KMeans (KMeans.scala) ---- */
 /* KMeans.init (KMeans.scala:188-196) */
-NAT(void, kmeansInit)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint k, jint seed, jfloatArray centsOut) {
+NAT(void, kmeansInit)(JNIEnv *env, jobject self, jlong ds, jint from, jint s, jint k, jint seed, jfloatArray centsOut) {
   pin_t co;
   if (pin(env, &co, centsOut, 0, OUT, 0)) return;
   int32_t rc = gulon_kmeans_init(DS(ds), from, s, k, seed, (float *)co.p, NULL);
@@ -78,7 +83,7 @@ NAT(void, kmeansInit)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint k
   throw_status(env, rc);
 }
 /* KMeans.assign / parAssign (KMeans.scala:18-22,57-98): rngBatch 0 = serial stream, 25000 = parAssign. */
-NAT(void, kmeansAssign)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jfloatArray centroids, jint k, jint rngBatch,
+NAT(void, kmeansAssign)(JNIEnv *env, jobject self, jlong ds, jint from, jint s, jfloatArray centroids, jint k, jint rngBatch,
                         jintArray assignments) {
   pin_t ce, as;
   if (pin(env, &ce, centroids, 0, IN, 0)) return;
@@ -88,7 +93,7 @@ NAT(void, kmeansAssign)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jflo
   throw_status(env, rc);
 }
 /* KMeans.fromAssignment (KMeans.scala:198-226) */
-NAT(void, kmeansUpdate)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint k, jintArray assignments,
+NAT(void, kmeansUpdate)(JNIEnv *env, jobject self, jlong ds, jint from, jint s, jint k, jintArray assignments,
                         jfloatArray centsOut) {
   pin_t as, co;
   if (pin(env, &as, assignments, 1, IN, 0)) return;
@@ -98,7 +103,7 @@ NAT(void, kmeansUpdate)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint
   throw_status(env, rc);
 }
 /* KMeans#iterate (KMeans.scala:100-106) */
-NAT(void, kmeansIterate)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jfloatArray centsIn, jint k, jint iters,
+NAT(void, kmeansIterate)(JNIEnv *env, jobject self, jlong ds, jint from, jint s, jfloatArray centsIn, jint k, jint iters,
                          jfloatArray centsOut) {
   pin_t ci, co;
   if (pin(env, &ci, centsIn, 0, IN, 0)) return;
@@ -116,7 +121,7 @@ static void unpack_reports(const gulon_kmeans_report *reps, int n, jint *ri, jfl
   }
 }
 /* KMeans.computeClusters (KMeans.scala:134-157) */
-NAT(void, kmeansTrain)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint k, jint maxIterations, jint seed,
+NAT(void, kmeansTrain)(JNIEnv *env, jobject self, jlong ds, jint from, jint s, jint k, jint maxIterations, jint seed,
                        jfloatArray centsOut, jintArray reportInts, jfloatArray reportFloats, jint maxReports,
                        jintArray nReports) {
   pin_t co, ri, rf, nr;
@@ -137,7 +142,7 @@ NAT(void, kmeansTrain)(JNIEnv *env, jclass c, jlong ds, jint from, jint s, jint 
 
 /* ---- ProductQuantizer (ProductQuantizer.scala) ---- */
 /* ProductQuantizer.apply (ProductQuantizer.scala:150-153): k*d floats out, quantizer j at k*from_j. */
-NAT(void, pqTrain)(JNIEnv *env, jclass c, jlong ds, jint m, jint k, jint maxIterations, jfloatArray centsOut,
+NAT(void, pqTrain)(JNIEnv *env, jobject self, jlong ds, jint m, jint k, jint maxIterations, jfloatArray centsOut,
                    jintArray reportInts, jfloatArray reportFloats, jint maxReports, jintArray nReports) {
   pin_t co, ri, rf, nr;
   if (maxReports < 0 || m < 1) { throw_named(env, "java/lang/IllegalArgumentException", "bad report shape"); return; }
@@ -155,7 +160,7 @@ NAT(void, pqTrain)(JNIEnv *env, jclass c, jlong ds, jint m, jint k, jint maxIter
   throw_status(env, rc);
 }
 /* ProductQuantizer.encode (ProductQuantizer.scala:25-35): m packed code arrays back to back. */
-NAT(void, pqEncode)(JNIEnv *env, jclass c, jlong ds, jint m, jint k, jfloatArray cents, jbyteArray codesOut) {
+NAT(void, pqEncode)(JNIEnv *env, jobject self, jlong ds, jint m, jint k, jfloatArray cents, jbyteArray codesOut) {
   pin_t ce, co;
   if (pin(env, &ce, cents, 0, IN, 0)) return;
   if (pin(env, &co, codesOut, 2, OUT, 0)) { unpin(env, &ce); return; }
@@ -166,7 +171,7 @@ NAT(void, pqEncode)(JNIEnv *env, jclass c, jlong ds, jint m, jint k, jfloatArray
 
 /* ---- Index (Index.scala) ---- */
 /* Index.prepareQuery (Index.scala:352-383): tablesOut[B][m][k] */
-NAT(void, prepareQuery)(JNIEnv *env, jclass c, jfloatArray cents, jint d, jint m, jint k, jfloatArray queries, jint b,
+NAT(void, prepareQuery)(JNIEnv *env, jobject self, jfloatArray cents, jint d, jint m, jint k, jfloatArray queries, jint b,
                         jfloatArray tablesOut) {
   pin_t ce, q, t;
   if (pin(env, &ce, cents, 0, IN, 0)) return;
@@ -177,7 +182,7 @@ NAT(void, prepareQuery)(JNIEnv *env, jclass c, jfloatArray cents, jint d, jint m
   throw_status(env, rc);
 }
 /* PQIndex(productQuantizer, data) (Index.scala:385-391). */
-NAT(jlong, indexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray cents,
+NAT(jlong, indexCreate)(JNIEnv *env, jobject self, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray cents,
                         jint rowBase) {
   gulon_index *ix = NULL;
   pin_t co, ce;
@@ -188,9 +193,9 @@ NAT(jlong, indexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, jint d,
   if (throw_status(env, rc)) return 0;
   return (jlong)(intptr_t)ix;
 }
-NAT(void, indexDestroy)(JNIEnv *env, jclass c, jlong h) { gulon_index_destroy((gulon_index *)(intptr_t)h); }
+NAT(void, indexDestroy)(JNIEnv *env, jobject self, jlong h) { gulon_index_destroy((gulon_index *)(intptr_t)h); }
 /* another workspace over the same device-resident codes (one per querying thread / batch in flight) */
-NAT(jlong, indexContextCreate)(JNIEnv *env, jclass c, jlong h) {
+NAT(jlong, indexContextCreate)(JNIEnv *env, jobject self, jlong h) {
   gulon_index *ctx = NULL;
   if (throw_status(env, gulon_index_context_create((gulon_index *)(intptr_t)h, &ctx))) return 0;
   return (jlong)(intptr_t)ctx;
@@ -220,17 +225,17 @@ static void query_common(JNIEnv *env, int which, jlong h, jfloatArray queries, j
   throw_status(env, rc);
 }
 /* PQIndex.batchQuery(k, vectors, from, until) (Index.scala:417-440) + Result.fromHeap (:83-94). */
-NAT(void, indexBatchQuery)(JNIEnv *env, jclass c, jlong h, jfloatArray queries, jint b, jint k, jint from, jint until,
+NAT(void, indexBatchQuery)(JNIEnv *env, jobject self, jlong h, jfloatArray queries, jint b, jint k, jint from, jint until,
                            jintArray outIdx, jfloatArray outDist, jintArray outCount, jintArray outFlags) {
   query_common(env, 0, h, queries, b, k, from, until, outIdx, outDist, outCount, outFlags);
 }
 /* Index.exactNearestNeighbours (Index.scala:209-229) for B queries over rows [from, until) */
-NAT(void, exactKnn)(JNIEnv *env, jclass c, jlong ds, jint from, jint until, jfloatArray queries, jint b, jint k,
+NAT(void, exactKnn)(JNIEnv *env, jobject self, jlong ds, jint from, jint until, jfloatArray queries, jint b, jint k,
                     jintArray outIdx, jfloatArray outDist, jintArray outCount, jintArray outFlags) {
   query_common(env, 2, ds, queries, b, k, from, until, outIdx, outDist, outCount, outFlags);
 }
 /* TopKHeap.merge across partial lists (TopKHeap.scala:44-53): lists [lists][B][K+1], ascending, (+inf, MAX) padded */
-NAT(void, topkMerge)(JNIEnv *env, jclass c, jfloatArray partDist, jintArray partIdx, jint lists, jint b, jint k,
+NAT(void, topkMerge)(JNIEnv *env, jobject self, jfloatArray partDist, jintArray partIdx, jint lists, jint b, jint k,
                      jintArray outIdx, jfloatArray outDist, jintArray outCount, jintArray outFlags) {
   pin_t pd, pi, oi, od, oc, of;
   if (pin(env, &pd, partDist, 0, IN, 0)) return;
@@ -246,7 +251,7 @@ NAT(void, topkMerge)(JNIEnv *env, jclass c, jfloatArray partDist, jintArray part
 }
 
 /* ---- PQIndex row-sharded over the GPUs of the node, inside this one JVM (sharded.hip: RCCL all-gathers) ---- */
-NAT(jlong, shardedIndexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray cents,
+NAT(jlong, shardedIndexCreate)(JNIEnv *env, jobject self, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray cents,
                                jintArray devices) {
   gulon_sharded_index *sx = NULL;
   pin_t co, ce, dv;
@@ -260,14 +265,14 @@ NAT(jlong, shardedIndexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, 
   if (throw_status(env, rc)) return 0;
   return (jlong)(intptr_t)sx;
 }
-NAT(void, shardedIndexDestroy)(JNIEnv *env, jclass c, jlong h) { gulon_sharded_index_destroy((gulon_sharded_index *)(intptr_t)h); }
-NAT(void, shardedIndexBatchQuery)(JNIEnv *env, jclass c, jlong h, jfloatArray queries, jint b, jint k, jintArray outIdx,
+NAT(void, shardedIndexDestroy)(JNIEnv *env, jobject self, jlong h) { gulon_sharded_index_destroy((gulon_sharded_index *)(intptr_t)h); }
+NAT(void, shardedIndexBatchQuery)(JNIEnv *env, jobject self, jlong h, jfloatArray queries, jint b, jint k, jintArray outIdx,
                                   jfloatArray outDist, jintArray outCount, jintArray outFlags) {
   query_common(env, 1, h, queries, b, k, 0, 0, outIdx, outDist, outCount, outFlags);
 }
 
 /* ---- GroupedIndex (Index.scala:231-308) ---- */
-NAT(jlong, groupResiduals)(JNIEnv *env, jclass c, jlong ds, jintArray perm, jintArray groupOf, jfloatArray centroids, jint g) {
+NAT(jlong, groupResiduals)(JNIEnv *env, jobject self, jlong ds, jintArray perm, jintArray groupOf, jfloatArray centroids, jint g) {
   gulon_dataset *out = NULL;
   pin_t p, go, ce;
   if (pin(env, &p, perm, 1, IN, 0)) return 0;
@@ -278,7 +283,7 @@ NAT(jlong, groupResiduals)(JNIEnv *env, jclass c, jlong ds, jintArray perm, jint
   if (throw_status(env, rc)) return 0;
   return (jlong)(intptr_t)out;
 }
-NAT(jlong, groupedIndexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray pqCents,
+NAT(jlong, groupedIndexCreate)(JNIEnv *env, jobject self, jbyteArray codes, jint n, jint d, jint m, jint k, jfloatArray pqCents,
                                jfloatArray groupCents, jintArray offsets, jint g) {
   gulon_grouped_index *out = NULL;
   pin_t co, pc, gc, of;
@@ -292,9 +297,9 @@ NAT(jlong, groupedIndexCreate)(JNIEnv *env, jclass c, jbyteArray codes, jint n, 
   if (throw_status(env, rc)) return 0;
   return (jlong)(intptr_t)out;
 }
-NAT(void, groupedIndexDestroy)(JNIEnv *env, jclass c, jlong h) { gulon_grouped_index_destroy((gulon_grouped_index *)(intptr_t)h); }
+NAT(void, groupedIndexDestroy)(JNIEnv *env, jobject self, jlong h) { gulon_grouped_index_destroy((gulon_grouped_index *)(intptr_t)h); }
 /* strategy 0 = LimitGroups, 1 = LimitVectors */
-NAT(void, groupedIndexBatchQuery)(JNIEnv *env, jclass c, jlong h, jfloatArray queries, jint b, jint k, jint strategy,
+NAT(void, groupedIndexBatchQuery)(JNIEnv *env, jobject self, jlong h, jfloatArray queries, jint b, jint k, jint strategy,
                                   jint limit, jintArray outIdx, jfloatArray outDist, jintArray outCount) {
   query_common(env, 3, h, queries, b, k, strategy, limit, outIdx, outDist, outCount, NULL);
 }

@@ -6,10 +6,11 @@ C3: 10 M x 300, KMeans codebook training, m = 32 -> ragged sub-dimensions 12 x 1
     (KMeans.scala:24-55), the chain update (KMeans.scala:198-226), ProductQuantizer.apply / encode
     (ProductQuantizer.scala:25-35,121-153).
 C5: 10 M x 1024, PQ m = 64 -> s = 16, k = 256: prepareQuery at s = 16 (Index.scala:352-383), the
-    2-query-interleaved exact scan (64 KiB of fp32 table per query), filter switch on and off
-    (m = 64 is outside the 8-bit filter's m_pad <= 36, so both settings must take the exact scan and
-    agree).  BASELINE's "fp16 distance tables" have no reference counterpart: the path
-    here keeps fp32 tables and is bit-exact; no fp16 mode is built.
+    2-query-interleaved exact scan (64 KiB of fp32 table per query) and the quantized filter in its
+    8-queries-per-entry form (m_pad * 1 KiB <= 144 KiB: m = 64 is eligible, filter.hip filter_eligible) --
+    the test asserts through gulon_index_filter_stats that the filter path really ran when it is switched on
+    and that the exact scan ran when it is off.  BASELINE's "fp16 distance tables" have no reference
+    counterpart: the path here keeps fp32 tables and is bit-exact; no fp16 mode is built.
 Everything is compared bit for bit with the oracle."""
 import ctypes as C
 
@@ -99,6 +100,10 @@ def test_c5_shape_train_encode_query_bit_exact(oracle, g, filt):
     g.native.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", filt))
     try:
         res = index.batch_query(K, Q)
+        tiles, redone = C.c_int32(-1), C.c_int32(-1)
+        g.native.check(L.gulon_index_filter_stats(index.vector_index._h, C.byref(tiles), C.byref(redone)))
+        # 40 000 rows >= the filter's minimum range: switched on, the whole-range query must have taken it
+        assert (tiles.value > 0) == bool(filt), (filt, tiles.value)
         sub = index.vector_index.batch_query(K, Q, 777, 33333)
     finally:
         g.native.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 1))
