@@ -445,7 +445,12 @@ __global__ void pack_centroids_split(const float *__restrict__ C, const float *_
   const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
   if (t0 < nkb * 64) {
     const int l = t0 & 63, kb = t0 >> 6;
-    const int c = kb * 32 + (l & 31), e0 = 8 * (l >> 5);
+    // Which centroid sits in which row of the A operand is ours to choose.  The 32x32 result leaves a lane with rows
+    // 8g + 4h + t (g, t = 0..3; h = lane / 32): row i = 8g + 4h + t carries centroid 16h + 4g + t of the block, so that
+    // the lower half-wave ends up with the block's centroids 0..15 and the upper one with 16..31, each in register order
+    // (assign_bf16 scans its 16 in order and the two halves meet once per block).
+    const int i = l & 31;
+    const int c = kb * 32 + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3), e0 = 8 * (l >> 5);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (c < k && e0 + e < s) ? -2.0f * C[(size_t)c * s + e0 + e] : 0.f;
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
   __syncthreads();
   const float cmax2 = __uint_as_float(*cmax2_bits);
   const int half = lane >> 5;
+  const bool upper = half != 0;
 
   // B operands of the NEXT tile pair are loaded while the current one is in the matrix pipe
   const long long pstride = (long long)gridDim.x * 4;
@@ -495,27 +501,45 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     nxn = row < n ? xn[row] : 0.f;
   };
   load_pair((long long)blockIdx.x * 4 + wave);
+  f32x16 ax, ay, bx2, by2;
+  bool have_acc = false;             // (ax, ay) already hold this pair's first block
   for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += pstride) {
     bf16x8 bx[3], by[3];
 #pragma unroll
     for (int p = 0; p < 3; p++) { bx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); by[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
-    const float nx = nxn;            // |x|^2 of the row this lane owns after the swaps (row pp*64 + lane)
+    const float nx = nxn;            // |x|^2 of the row this lane answers for (row pp*64 + lane)
     load_pair(pp + pstride);
     // 2E band (see file header); non-finite inputs make it NaN => row flagged below
     const float e2 = errk * (cmax2 + 2.0f * __fsqrt_rn(nx * cmax2)) + 1e-30f;
 
-    float pmin = FLT_MAX;      // running minimum key
-    float mband = INFINITY;    // smallest |key - running minimum| seen by this row's scan
-    int best = -1;
+    // The scan of a row's 32 distances to a centroid block is the reference's: in centroid order, every key against
+    // the running minimum of the keys before it.  A row's 32 distances sit in TWO lanes (l and l + 32, 16 each: the
+    // matrix core's result layout).  Round 2 brought them into one lane with 16 v_permlane32_swap per block --
+    // 19 cycles each, 300 of the ~1200 cycles a wave spent per block.  Here the row order of the A operand puts the
+    // block's centroids 0..15 into the lower half-wave and 16..31 into the upper one, and the scan takes two passes
+    // over the accumulators, both halves and both row tiles working side by side:
+    //   pass 1  every lane: the minimum of its 16 keys (a tree of v_min3: no order inside a half is needed for it);
+    //           ONE exchange per tile and block tells the upper half where the lower half left the running minimum;
+    //   pass 2  every lane scans its 16 keys in order from the state it now knows: the minimum before the block for
+    //           the lower half, min(that, the lower half's 16) for the upper half.
+    // Running minimum and the centroid it sits at are the same in both lanes of a row afterwards; the band distance
+    // accumulates per lane and the two are combined once per tile pair.  A key carries its register number (4 bits:
+    // 15 ulp of perturbation instead of 31); which half a block's minimum came from is read off the two minima.
+    struct Scan {
+      float pin;       // running minimum key before the current block (both lanes of a row agree)
+      float mband;     // smallest |key - running minimum| this LANE saw
+      int best;        // centroid of the running minimum (-1: none yet)
+    };
+    Scan sx{FLT_MAX, INFINITY, -1}, sy{FLT_MAX, INFINITY, -1};
 
     auto init_block = [&](int kb, f32x16 &ax, f32x16 &ay, bf16x8 (&a)[3]) {
-      const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 4 * half);
-      const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 4 * half);
+      const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 16 * half);
+      const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 16 * half);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        float4 o = so[2 * g];   // centroids 8g + 4*half + (0..3)
+        float4 o = so[g];       // centroids 16 * half + 4 g + (0..3) = registers 4 g + (0..3)
         ax[4 * g + 0] = o.x; ax[4 * g + 1] = o.y; ax[4 * g + 2] = o.z; ax[4 * g + 3] = o.w;
-        float4 o2 = so2[2 * g];
+        float4 o2 = so2[g];
         ay[4 * g + 0] = o2.x; ay[4 * g + 1] = o2.y; ay[4 * g + 2] = o2.z; ay[4 * g + 3] = o2.w;
       }
 #pragma unroll
@@ -529,86 +553,146 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       if (m & 1) ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], by[pb[t]], ay, 0, 0, 0);
       else ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], bx[pb[t]], ax, 0, 0, 0);
     };
-    // piece h (0..7) of the scan epilogue: see assign_mfma<T>
-    auto scan_piece = [&](int h, f32x16 &ax, f32x16 &ay) {
-      if ((h & 1) == 0) {
-#pragma unroll
-        for (int r = 4 * (h >> 1); r < 4 * (h >> 1) + 4; r++) {
-          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax[r]), __float_as_uint(ay[r]), false, false);
-          ax[r] = __uint_as_float(sw[0]);
-          ay[r] = __uint_as_float(sw[1]);
-        }
-      }
-      unsigned key[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int j = 4 * h + e;
-        const float v = (h & 1) ? ay[4 * (h >> 1) + e] : ax[4 * (h >> 1) + e];
-        key[e] = (__float_as_uint(v) & ~31u) | (unsigned)j;
-      }
+    auto fmin3 = [](float a, float b, float c) {
+      float r;
+      asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+      return r;
+    };
+    auto fmin2 = [](float a, float b) {
+      float r;
+      asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      return r;
+    };
+    // the minimum of a lane's 16 keys (a tree: no order needed)
+    auto min16 = [&](const f32x16 &acc) {
+      const float m0 = fmin3(acc[0], acc[1], acc[2]), m1 = fmin3(acc[3], acc[4], acc[5]);
+      const float m2 = fmin3(acc[6], acc[7], acc[8]), m3 = fmin3(acc[9], acc[10], acc[11]);
+      const float m4 = fmin3(acc[12], acc[13], acc[14]);
+      return fmin2(fmin3(m0, m1, m2), fmin3(m3, m4, acc[15]));
+    };
+    // pass 2 over keys r0 .. r0 + 3 of one tile, from running minimum p
+    auto scan4 = [&](const f32x16 &acc, int r0, float &p, float &mband) {
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
-        const float k0 = __uint_as_float(key[e]), k1 = __uint_as_float(key[e + 1]);
-        float q0, q1;
-        asm("v_min_f32 %0, %1, %2" : "=v"(q0) : "v"(pmin), "v"(k0));
-        asm("v_min_f32 %0, %1, %2" : "=v"(q1) : "v"(q0), "v"(k1));
-        const float d0 = k0 - pmin, d1 = k1 - q0;
+        const float k0 = acc[r0 + e], k1 = acc[r0 + e + 1];
+        const float q0 = fmin2(p, k0), q1 = fmin2(q0, k1);
+        const float d0 = k0 - p, d1 = k1 - q0;
         asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
-        pmin = q1;
+        p = q1;
       }
     };
-    auto step = [&](auto next_tag, int kb, f32x16 &sx, f32x16 &sy, f32x16 &nx_, f32x16 &ny_) {
+    // after a block: the row's running minimum and where it sits.  lo / hi = the minima of the block's first and
+    // second 16 centroids (both lanes of a row hold both after the exchange); branch-free
+    auto close_block = [&](Scan &st, int kb, float lo, float hi) {
+      const float blk = fmin2(lo, hi);
+      // equal keys of the two halves (same distance bits, same register): the lower half's centroid comes first
+      const int cand = kb * 32 + (hi < lo ? 16 : 0) + (int)(__float_as_uint(blk) & 15u);
+      const bool better = blk < st.pin;                 // (a NaN never wins: such a row is flagged by its band)
+      st.best = better ? cand : st.best;
+      st.pin = better ? blk : st.pin;
+    };
+    // One block: the scan of the accumulators (cx, cy) while the matrix instructions of the NEXT block -- the same row
+    // tiles against centroid block kb + 1, or, at a pair's last block, the next pair's tiles against block 0 -- fill
+    // (nx_, ny_).  Twelve matrix instructions, twelve slices of vector work between them: a matrix instruction
+    // that depends on the one two slices back (same accumulator) never waits, and neither does the wave's issue.
+    auto step = [&](auto next_tag, int kb, int kb_next, f32x16 &cx, f32x16 &cy, f32x16 &nx_, f32x16 &ny_,
+                    const bf16x8 (&nbx)[3], const bf16x8 (&nby)[3]) {
       constexpr bool NEXT = decltype(next_tag)::value;
       bf16x8 a[3];
-      if (NEXT) init_block(kb + 1, nx_, ny_, a);
-      const float qbefore = pmin;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int h = 0; h < 8; h++) {
-        if (NEXT) {
-#pragma unroll
-          for (int m = 0; m < 12; m++)
-            if (m * 8 / 12 == h) one_mfma(m, nx_, ny_, a);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        scan_piece(h, sx, sy);
+      auto mf = [&](int m) {
+        if (!NEXT) return;
+        constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+        const int t = m >> 1;
+        if (m & 1) ny_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], nby[pb[t]], ny_, 0, 0, 0);
+        else nx_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], nbx[pb[t]], nx_, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+      };
+      if (NEXT) init_block(kb_next, nx_, ny_, a);
+      __builtin_amdgcn_sched_barrier(0);
+      // pass 1: keys, minima of the 16, exchange
+#pragma unroll
+      for (int r = 0; r < 16; r++) cx[r] = __uint_as_float((__float_as_uint(cx[r]) & ~15u) | (unsigned)r);
+      mf(0);
+#pragma unroll
+      for (int r = 0; r < 16; r++) cy[r] = __uint_as_float((__float_as_uint(cy[r]) & ~15u) | (unsigned)r);
+      mf(1);
+      const float mx = min16(cx), my = min16(cy);
+      // permlane32_swap(a, b): a's upper half <-> b's lower half.  With a = b = m: the first result is the LOWER lane's
+      // value in both lanes of a row, the second the UPPER lane's
+      auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(my), __float_as_uint(my), false, false);
+      const float lox = __uint_as_float(s1[0]), hix = __uint_as_float(s1[1]);
+      const float loy = __uint_as_float(s2[0]), hiy = __uint_as_float(s2[1]);
+      // the lower half starts from the minimum before the block, the upper half from min(that, the lower half's 16)
+      float px = fmin2(sx.pin, upper ? lox : FLT_MAX);
+      float py = fmin2(sy.pin, upper ? loy : FLT_MAX);
+      mf(2);
+      // pass 2
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        scan4(cx, 4 * h, px, sx.mband);
+        mf(3 + 2 * h);
+        scan4(cy, 4 * h, py, sy.mband);
+        mf(4 + 2 * h);
       }
-      if (__float_as_uint(pmin) != __float_as_uint(qbefore)) best = kb * 32 + (int)(__float_as_uint(pmin) & 31u);
+      close_block(sx, kb, lox, hix);
+      close_block(sy, kb, loy, hiy);
+      mf(11);
     };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
 
-    f32x16 ax, ay, bx2, by2;
-    {
+    if (!have_acc) {               // the pair's first block (a pair's last step leaves it ready: see below)
       bf16x8 a0[3];
       init_block(0, ax, ay, a0);
 #pragma unroll
       for (int m = 0; m < 12; m++) one_mfma(m, ax, ay, a0);
     }
-    if (probe) {   // selftest: raw distances of (first 64 rows) x (centroid block 0), before any swap
+    if (probe) {   // selftest: raw distances of (first 64 rows) x (centroid block 0)
       if (blockIdx.x == 0 && wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+          const int c = 16 * half + r;
           probe[(size_t)(lane & 31) * 32 + c] = ax[r];
           probe[(size_t)(32 + (lane & 31)) * 32 + c] = ay[r];
         }
       }
       return;
     }
+    // the NEXT pair's B operands (requested at the top of this iteration, one whole pair ahead)
+    bf16x8 fx[3], fy[3];
+    const bool more = pp + pstride < npairs;
     int kb = 0;
     for (; kb + 2 < nkb; kb += 2) {
-      step(Yes{}, kb, ax, ay, bx2, by2);
-      step(Yes{}, kb + 1, bx2, by2, ax, ay);
+      step(Yes{}, kb, kb + 1, ax, ay, bx2, by2, bx, by);
+      step(Yes{}, kb + 1, kb + 2, bx2, by2, ax, ay, bx, by);
     }
     if (kb + 1 < nkb) {
-      step(Yes{}, kb, ax, ay, bx2, by2);
-      step(No{}, kb + 1, bx2, by2, ax, ay);
+      step(Yes{}, kb, kb + 1, ax, ay, bx2, by2, bx, by);
+      // an even number of blocks: the last step's idle accumulators are (ax, ay) again -- the next pair's first block
+      // goes there, its twelve matrix instructions between this block's vector work instead of in a row of their own
+#pragma unroll
+      for (int p = 0; p < 3; p++) { fx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); fy[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
+      if (more) { step(Yes{}, kb + 1, 0, bx2, by2, ax, ay, fx, fy); have_acc = true; }
+      else { step(No{}, kb + 1, 0, bx2, by2, ax, ay, fx, fy); have_acc = false; }
     } else {
-      step(No{}, kb, ax, ay, bx2, by2);
+      step(No{}, kb, 0, ax, ay, bx2, by2, bx, by);
+      have_acc = false;
     }
 
+    // a row's band distance = the smaller of its two lanes' (NaN if either is); lane l < 32 answers for row l of
+    // tile X, lane l >= 32 for row l - 32 of tile Y
+    float mband;
+    {
+      // after the swap: r[0] = {lower lanes: their X band, upper lanes: the lower lanes' Y band},
+      //                 r[1] = {lower lanes: the upper lanes' X band, upper lanes: their Y band}
+      auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(sx.mband), __float_as_uint(sy.mband), false, false);
+      const float mine = upper ? sy.mband : sx.mband;
+      const float theirs = __uint_as_float(upper ? sb[0] : sb[1]);
+      mband = (mine == mine && theirs == theirs) ? fminf(mine, theirs) : NAN;
+    }
+    const float pmin = upper ? sy.pin : sx.pin;
+    const int best = upper ? sy.best : sx.best;
     const long long row = pp * 64 + lane;
     const bool in_range = row < n;
     const bool my_amb = !(mband > e2);   // also true when mband is NaN
@@ -631,7 +715,7 @@ static bool mfma_split(int s, int k) {
 }
 static float split_errk(int s) {
   // band = 2.1 * E + key perturbation (see the kernel's header): E / S = [(s+1) + 6 (s+2)] 2^-24 + 2^-22.9
-  return 2.1f * ((float)(7 * s + 13) * 5.9604645e-8f + 1.28e-7f) + 2.1f * 31.0f * 1.1920929e-7f;
+  return 2.1f * ((float)(7 * s + 13) * 5.9604645e-8f + 1.28e-7f) + 2.1f * 15.0f * 1.1920929e-7f;   // (4 index bits in a key)
 }
 
 // K-steps of the kernel that handles (s, k): the resident-A kernel when all A operands fit LDS and
