@@ -150,6 +150,7 @@ void launch_conflict_order(const uint8_t *src, uint8_t *dst, uint8_t *perm, long
 
 using namespace gulon;
 
+#ifdef GULON_TEST_HOOKS
 GULON_API int32_t gulon_selftest_conflict_order(const uint8_t *codes, int64_t n_blocks, int32_t rounds, uint8_t *codes_out,
                                                 uint8_t *place_out) {
   return guarded([&] {
@@ -164,4 +165,4 @@ GULON_API int32_t gulon_selftest_conflict_order(const uint8_t *codes, int64_t n_
     HIP_CHECK(hipMemcpy(place_out, place.p, (size_t)n_blocks * 64, hipMemcpyDeviceToHost));
   });
 }
-
+#endif

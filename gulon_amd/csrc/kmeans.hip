@@ -652,6 +652,12 @@ __device__ __forceinline__ float mean_quotient_fast(float a, float nf, float y) 
   const float r = __builtin_fmaf(-nf, q0, a);
   return __builtin_fmaf(r, y, q0);
 }
+// The proofs of the corrected quotient single out divisors whose significand is all ones (for integers: n = 2^j - 1)
+// as the ones for which a numerator can exist that the correction rounds the other way; the sampled self-test
+// cannot rule such a numerator out, so these ~24 divisors never take the fast path: a batch of 32 steps, divisors
+// 32 b + 1 .. 32 b + 32, holds one iff b + 1 is a power of two (b = 0: 1, 3, 7, 15, 31) -- two dozen batches of a
+// chain's thousands go through __fdiv_rn.
+__device__ __forceinline__ bool batch_has_all_ones_divisor(unsigned b) { return ((b + 1u) & b) == 0u; }
 __device__ __forceinline__ bool mean_fast_ok(float a) {
   const float m = fabsf(a);
   return m > 8.673617379884035e-19f /* 2^-60 */ && m < 1.152921504606847e18f /* 2^60 */;
@@ -662,6 +668,7 @@ __global__ void rcp_table_kernel(float *__restrict__ out, long long n) {
   if (i < n) out[i] = __fdiv_rn(1.0f, (float)(int)(i + 1));
 }
 
+#ifdef GULON_TEST_HOOKS
 // mismatches of mean_quotient_fast against __fdiv_rn: every divisor n in [1, n_max], `per` numerators each --
 // random ones and ones built to sit next to a rounding boundary (n times a random quotient, one ulp up and down)
 __global__ void mean_division_selftest(int n_max, int per, unsigned long long seed, unsigned long long *__restrict__ bad) {
@@ -692,6 +699,7 @@ __global__ void mean_division_selftest(int n_max, int per, unsigned long long se
   }
   if (mism) atomicAdd(bad, mism);
 }
+#endif
 
 // one thread per (cluster, dim): c_j <- c_j + (x_j - c_j)/n over the cluster's rows
 // in row order (KMeans.scala:211-224); int->float RNE, correctly rounded quotient (above).
@@ -745,8 +753,10 @@ __global__ __launch_bounds__(64) void update_chains(const UpdDesc *__restrict__ 
         p = p + mean_quotient_fast(a, nf, rcp[i + u]);
         nf += 1.0f;                                   // exact below 2^24
       }
-      // a zero, tiny, huge or NaN numerator somewhere in the batch: the plain division, from the batch's start
-      if (!__all(lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */)) {
+      // a zero, tiny, huge or NaN numerator somewhere in the batch, or a divisor whose significand is all ones
+      // (2^j - 1: see mean_quotient_fast) among its 32: the plain division, from the batch's start
+      if (!__all(lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */) ||
+          batch_has_all_ones_divisor(i / U)) {
         p = p0;
 #pragma unroll
         for (int u = 0; u < U; u++) p = p + __fdiv_rn(xa[u] - p, (float)(int)(i + u + 1));
@@ -844,8 +854,10 @@ __global__ __launch_bounds__(64) void update_chains_pk(const UpdDesc *__restrict
         const f32x2 r = __builtin_elementwise_fma(nn, q0, a);
         p = p + __builtin_elementwise_fma(r, y2, q0);
       }
-      // a zero, tiny, huge or NaN numerator somewhere in a live lane's batch: the plain division, from the batch's start
-      if (!__all(!live || (lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */))) {
+      // a zero, tiny, huge or NaN numerator somewhere in a live lane's batch, or a divisor whose significand is all ones
+      // (2^j - 1: see mean_quotient_fast) among its 32: the plain division, from the batch's start
+      if (!__all(!live || (lo > 8.673617379884035e-19f /* 2^-60 */ && hi < 1.152921504606847e18f /* 2^60 */)) ||
+          batch_has_all_ones_divisor(b)) {
         p = p0;
 #pragma unroll
         for (int u = 0; u < U; u++) p = slow(p, cur[u], i + u + 1);
@@ -1197,7 +1209,9 @@ void kmeans_update_batch(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, in
     for (const UpdDesc &D : descs) kmeans_update_bigk(D, d_descs, n, k, st);
     return;
   }
-  if (kmeans_update_fused(descs, d_descs, n, k, st)) return;   // chains straight from the unsorted slices (kmeans_fused.hip)
+#ifdef GULON_TEST_HOOKS
+  if (kmeans_update_fused(descs, d_descs, n, k, st)) return;   // the measured-and-dropped fused update (kmeans_fused.hip; GULON_UPDATE_FUSED=1)
+#endif
   HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(UpdDesc) * np, hipMemcpyHostToDevice, st));
   int smax = 1;
   for (const UpdDesc &D : descs) smax = std::max(smax, D.s);
@@ -1524,6 +1538,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
 
 using namespace gulon;
 
+#ifdef GULON_TEST_HOOKS
 GULON_API int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed,
                                                int64_t *mismatches) {
   return guarded([&] {
@@ -1538,6 +1553,7 @@ GULON_API int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators
     *mismatches = (int64_t)h;
   });
 }
+#endif
 
 GULON_API int32_t gulon_kmeans_trace(int32_t enable) {
   return guarded([&] {

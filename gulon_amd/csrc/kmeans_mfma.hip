@@ -899,9 +899,11 @@ double selftest_assign_band(int s, unsigned long long seed, float scale) {
 
 }  // namespace gulon
 
+#ifdef GULON_TEST_HOOKS
 GULON_API int32_t gulon_selftest_assign_band(int32_t s, uint64_t seed, float scale, double *max_error_over_band) {
   return gulon::guarded([&] {
     GULON_REQUIRE(max_error_over_band != nullptr && s >= 1 && s <= 16, "bad arguments");
     *max_error_over_band = gulon::selftest_assign_band(s, seed, scale);
   });
 }
+#endif

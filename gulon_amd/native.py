@@ -82,9 +82,6 @@ SIGNATURES = {
     "gulon_kmeans_iterate": (_i32, [_vp, _i32, _i32, _f32p, _i32, _i32, _f32p]),
     "gulon_kmeans_train": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32,
                                   C.POINTER(_i32)]),
-    "gulon_selftest_mean_division": (_i32, [_i32, _i32, C.c_uint64, C.POINTER(C.c_int64)]),
-    "gulon_selftest_conflict_order": (_i32, [C.c_void_p, C.c_int64, _i32, C.c_void_p, C.c_void_p]),
-    "gulon_selftest_assign_band": (_i32, [_i32, C.c_uint64, C.c_float, C.POINTER(C.c_double)]),
     "gulon_kmeans_trace": (_i32, [_i32]),
     "gulon_kmeans_trace_read": (_i32, [C.POINTER(KMeansTraceTotals)]),
     "gulon_pq_train": (_i32, [_vp, _i32, _i32, _i32, _f32p, C.POINTER(KMeansReport), _i32, _vp]),
@@ -127,6 +124,31 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+# libgulon_hip_testhooks.so (tests only): the product library's objects plus the kernels' self-tests and the
+# measured-and-dropped fused k-means update (GULON_UPDATE_FUSED=1) -- include/gulon_hip.h under GULON_TEST_HOOKS
+HOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libgulon_hip_testhooks.so")
+TEST_HOOK_SIGNATURES = {
+    "gulon_selftest_mean_division": (_i32, [_i32, _i32, C.c_uint64, C.POINTER(C.c_int64)]),
+    "gulon_selftest_conflict_order": (_i32, [C.c_void_p, C.c_int64, _i32, C.c_void_p, C.c_void_p]),
+    "gulon_selftest_assign_band": (_i32, [_i32, C.c_uint64, C.c_float, C.POINTER(C.c_double)]),
+}
+_hooks = None
+
+
+def hooks_lib():
+    """The test-hook build of the library (tests only; nothing in gulon_amd calls it)."""
+    global _hooks
+    if _hooks is None:
+        L = C.CDLL(HOOKS_LIB_PATH)
+        for name, (res, args) in TEST_HOOK_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L.gulon_last_error.restype = C.c_char_p
+        _hooks = L
+    return _hooks
 
 
 def lib():

@@ -135,6 +135,7 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
                            int32_t max_iterations, int32_t seed, float *c_out,
                            gulon_kmeans_report *reports, int32_t max_reports, int32_t *n_reports);
 
+#ifdef GULON_TEST_HOOKS   /* libgulon_hip_testhooks.so only: the product library does not export these */
 /* Self-test of the running mean's division (kmeans.hip, update_chains): the three-operation quotient
  * q0 = RN(a y), r = fma(-n, q0, a), q = fma(r, y, q0) with y = RN(1/n) against the correctly rounded division
  * for every divisor n in [1, n_max] (n_max < 2^24) and `numerators_per_divisor` numerators each (random, and
@@ -152,6 +153,7 @@ int32_t gulon_selftest_conflict_order(const uint8_t *codes, int64_t n_blocks, in
  * outliers), d' = the matrix cores' value, d = the reference's unfused fp32 chain (KMeans.scala:42-47).  The filter
  * is sound while the result stays below 0.5 (the band is twice the error bound). */
 int32_t gulon_selftest_assign_band(int32_t s, uint64_t seed, float scale, double *max_error_over_band);
+#endif
 /* Stage times of the training loop for bench.py's k-means record (BASELINE config 3): while enabled, every
  * stage of KMeans.computeClusters / ProductQuantizer.apply is closed by a device synchronisation and its wall
  * time accumulated over the iterations (process-wide; not for concurrent trainings):

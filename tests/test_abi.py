@@ -10,9 +10,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
+def _header_symbols(hooks=False):
+    """Entry points include/gulon_hip.h declares: the product's, or (hooks=True) only those under GULON_TEST_HOOKS."""
     txt = open(os.path.join(ROOT, "include", "gulon_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    guarded = "".join(re.findall(r"#ifdef GULON_TEST_HOOKS(.*?)#endif", txt, flags=re.S))
+    if hooks:
+        txt = guarded
+    else:
+        txt = re.sub(r"#ifdef GULON_TEST_HOOKS.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gulon_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -32,6 +38,21 @@ def test_library_exports_every_declared_symbol():
     assert not extra, extra
     L = native.lib()
     assert L.gulon_abi_version() == 3
+
+
+def test_product_library_carries_no_test_hooks():
+    """Self-tests and the dropped fused-update experiment are in libgulon_hip_testhooks.so only."""
+    from gulon_amd import native
+    hooks = _header_symbols(hooks=True)
+    assert hooks == sorted(native.TEST_HOOK_SIGNATURES) and len(hooks) == 3
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {l.split()[-1] for l in out.splitlines() if " T " in l}
+    prod, hk = exported(native.LIB_PATH), exported(native.HOOKS_LIB_PATH)
+    assert not [s for s in prod if "selftest" in s]
+    assert set(hooks) <= hk and {s for s in prod if s.startswith("gulon_")} <= hk
+    sym = subprocess.check_output(["nm", "-C", native.LIB_PATH], text=True)
+    assert "update_fused" not in sym                       # the experiment's kernels are not linked into the product
 
 
 def test_host_only_entry_points_match_oracle(oracle):

@@ -350,7 +350,7 @@ def test_conflict_order_is_a_permutation_and_lowers_the_model_cost(g):
     codes[7, :, 3] = np.arange(64) * 16 % 256      # one quantizer whose codes all share a bank column
     out, place = np.empty_like(codes), np.empty((nblk, 64), np.uint8)
     for rounds in (0, 1, 2):
-        N.check(N.lib().gulon_selftest_conflict_order(codes.ctypes.data, nblk, rounds, out.ctypes.data, place.ctypes.data))
+        assert 0 == N.hooks_lib().gulon_selftest_conflict_order(codes.ctypes.data, nblk, rounds, out.ctypes.data, place.ctypes.data)
         assert np.array_equal(np.sort(place, axis=1), np.tile(np.arange(64, dtype=np.uint8), (nblk, 1)))
         assert np.array_equal(out, np.take_along_axis(codes, place[:, :, None].astype(np.int64), axis=1))
         if rounds == 0:

@@ -184,7 +184,7 @@ def test_mean_division_identity_holds_for_every_divisor(g):
     be THE correctly rounded quotient (KMeans.scala:218, the JVM's float division) for every n a cluster can reach."""
     import ctypes as C
     bad = C.c_int64(-1)
-    g.native.check(g.native.lib().gulon_selftest_mean_division((1 << 24) - 1, 96, 12345, C.byref(bad)))
+    assert 0 == g.native.hooks_lib().gulon_selftest_mean_division((1 << 24) - 1, 96, 12345, C.byref(bad))
     assert bad.value == 0
 
 
@@ -216,7 +216,7 @@ def test_bf16_split_filter_error_stays_inside_its_band(g, s):
     worst = 0.0
     for seed, scale in ((1, 1.0), (2, 1e-3), (3, 300.0), (4, 1e6), (5, 1e-12)):
         r = C.c_double(-1.0)
-        g.native.check(g.native.lib().gulon_selftest_assign_band(s, seed, scale, C.byref(r)))
+        assert 0 == g.native.hooks_lib().gulon_selftest_assign_band(s, seed, scale, C.byref(r))
         worst = max(worst, r.value)
     assert 0.0 <= worst < 0.5, worst
 
@@ -242,7 +242,8 @@ def test_fused_update_experiment_is_bit_exact():
             assert np.array_equal(bits(pq.flat_centroids()), bits(cents)), (n, d, m, k)
         print("fused ok")
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, GULON_UPDATE_FUSED="1")
+    import gulon_amd
+    env = dict(os.environ, GULON_UPDATE_FUSED="1", GULON_HIP_LIB=gulon_amd.native.HOOKS_LIB_PATH)   # the experiment lives in the test-hook build
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
 
