@@ -70,13 +70,29 @@ __global__ __launch_bounds__(64) void rp_collect(const int *__restrict__ flags, 
   if (lane == 0 && hint && skip == 0) *hint = base;
 }
 
+// (+ rlast[f], when the main pass's result is at hand: the last row that can still insert for flagged query f -- the
+// largest row id among its K best.  At any later row all K of them are in the reference's heap, its root is at most
+// the final K-th distance, and a row strictly below that distance would be one of the K best itself: no level of
+// the replay has to look past it.  INT_MAX: unknown / fewer than K results)
 __global__ void rp_gather_queries(const float *__restrict__ Q, int d, int maxf, const int *__restrict__ list,
-                                  const int *__restrict__ count, float *__restrict__ Qf) {
+                                  const int *__restrict__ count, float *__restrict__ Qf, int K,
+                                  const int *__restrict__ fin_i, const int *__restrict__ fin_c, int *__restrict__ rlast) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int f = t / d, c = t - f * d;
   if (f >= maxf) return;
   int nf = min(*count, maxf);
   Qf[t] = f < nf ? Q[(size_t)list[f] * d + c] : 0.f;
+  if (rlast && c == 0) {
+    int last = INT_MAX;
+    if (f < nf && fin_i) {
+      const int q = list[f];
+      if (q >= 0 && fin_c[q] == K) {
+        last = 0;
+        for (int i = 0; i < K; i++) last = max(last, fin_i[(size_t)q * K + i]);
+      }
+    }
+    rlast[f] = last;
+  }
 }
 
 template <int VEC> struct RpWord;
@@ -100,7 +116,8 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
                                                float *__restrict__ out_v, int *__restrict__ out_i,
                                                int *__restrict__ out_c, int pool, float *__restrict__ evv,
                                                int *__restrict__ evi, int *__restrict__ evcnt,
-                                               const int *__restrict__ only /* per flagged query; null: all */) {
+                                               const int *__restrict__ only /* per flagged query; null: all */,
+                                               const int *__restrict__ rlast /* per flagged query: last row that can insert; null: none known */) {
   using Word = typename RpWord<VEC>::type;
   extern __shared__ float tab[];   // m_pad * 256
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,6 +126,11 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
   // the grid has a fixed, small y extent; each block walks the flagged queries f = y, y+Y, ...
   for (int f = blockIdx.y; f < nf; f += gridDim.y) {
     if (only && only[f] != 1) continue;     // (uniform) 0: this query's rows came through the quantized filter; 2: rp_shortcut
+    // no row after rlast[f] inserts: a level that lies behind it has nothing to emit for this query (its seeds for
+    // the next level are not needed either: that level lies behind it as well)
+    int rb_stop = rb_hi;
+    if (rlast && rlast[f] != INT_MAX) rb_stop = min(rb_hi, max(0, ((rlast[f] - row_base) >> 6) + 1));
+    if (rb_lo >= rb_stop && !out_v) continue;          // (uniform; a level that feeds the next one still writes its lists)
     __syncthreads();
     {
       const float *src = tables + (size_t)f * m_pad * 256;
@@ -139,7 +161,7 @@ __global__ __launch_bounds__(256) void rp_scan(const uint8_t *__restrict__ codes
     };
     const Word *cw = reinterpret_cast<const Word *>(codes);
     const int rb0 = rb_lo + s * rb_per_seg;
-    const int rb1 = min(rb_hi, rb0 + rb_per_seg);
+    const int rb1 = min(rb_stop, rb0 + rb_per_seg);
     Word w_first{};
     if (rb0 < rb1) w_first = cw[((size_t)rb0 * ng) * 64 + lane];
     for (int rb = rb0; rb < rb1; rb++) {
@@ -533,8 +555,10 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   ix->rp_l0v.ensure((size_t)F * K); ix->rp_l0i.ensure((size_t)F * K); ix->rp_l0c.ensure(F);
   ix->rp_prefix.ensure((size_t)F * K); ix->rp_precnt.ensure(F);
   ix->rp_mins.ensure((size_t)(F + 16) * std::max(ix->m_pad, ix->m));
+  ix->rp_done.ensure((size_t)3 * F);
+  int *rlast_all = fin_i && !ix->wide ? ix->rp_done.p + 2 * F : nullptr;   // (rp_shortcut writes the same values again)
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)F * ix->d, 256)), dim3(256), 0, st, dQ, ix->d, F,
-                     pk.list(), pk.count(), ix->rp_q.p);
+                     pk.list(), pk.count(), ix->rp_q.p, K, fin_i, fin_c, rlast_all);
   if (ix->wide)   // (tables of all F slots: the flagged-query count stays on the device)
     launch_build_tables_wide(ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m, ix->k, ix->rp_q.p, 0, F, ix->rp_tables.p, st);
   else
@@ -555,7 +579,7 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
                                   (int)lds));
     hipLaunchKernelGGL(kern, dim3(ceil_div(nseg, 4), gy), dim3(256), lds, st, ix->codes.p, ix->ng, ix->m_pad,
                        ix->rp_tables.p, pk.count(), F, from, until, ix->row_base, rb_lo, rb_hi, per_seg, nseg, K, sv, sc,
-                       ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt(), only);
+                       ov, oi, oc, C, pk.evv(), pk.evi(), pk.evcnt(), only, rlast_all);
     HIP_CHECK(hipGetLastError());
   };
   // level 0: cold start over the first rows -> their K smallest distances
