@@ -132,6 +132,138 @@ __global__ __launch_bounds__(256) void conflict_order(const uint4 *__restrict__ 
   perm[blk * 64 + target] = (uint8_t)lane;
 }
 
+// ---- the same ordering over a WINDOW of four blocks (256 rows) ------------------------------------------------------
+// A row may land in any of the window's 4 x 4 lane groups: sixteen rows per group, 16 groups to balance instead of 4 --
+// simulated on uniform codes the model cost of a gather falls to 8.7 cycles against 9.6 inside one block (12.3 plain).
+// One workgroup per window, thread = row: for every row in turn its exchange with each of the other 255 rows is
+// evaluated by that row's thread (the exact change of the sum of the fullest columns, as above), the best one of the
+// workgroup is applied if it lowers the potential.  perm[block * 64 + lane] = the row's place in the WINDOW
+// (0 .. 255): a byte still.  A last window of fewer than four blocks orders its rows among the blocks it has.
+// What this asks of the readers of the copy: a block holds rows of its whole window, so a row range is scanned in
+// whole windows (filter.hip rounds its block range outwards and tests every reported row against the range).
+template <int NQ>
+__global__ __launch_bounds__(256) void conflict_order_window(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                             uint8_t *__restrict__ perm, long long nblk, int rounds) {
+  __shared__ uint32_t cnt_s[16 * 16 * 4];        // [group (16)][quantizer (16)][column] bytes, four columns per word
+  __shared__ uint16_t st_s[16 * 16];             // [group][quantizer] fullest column | number of such columns << 8
+  __shared__ uint8_t grp_s[256];                 // group of every row
+  __shared__ unsigned long long cols_s[256];     // bank columns of every row's 16 entries (one nibble each)
+  __shared__ int best_s[4];
+  __shared__ int rank_s[4][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long long wb = (long long)blockIdx.x * 4;                       // first block of the window
+  const int nrows = (int)min(256ll, (nblk - wb) * 64);                  // rows of the window (whole blocks)
+  const bool live = t < nrows;
+  uint8_t *cb = reinterpret_cast<uint8_t *>(cnt_s);
+  uint4 w = make_uint4(0, 0, 0, 0);
+  if (live) w = src[wb * 64 + t];
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+  unsigned long long cols = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) cols |= (unsigned long long)((ws[q >> 2] >> (8 * (q & 3))) & 15u) << (4 * q);
+  int grp = 4 * wave + lds_group_of_lane(lane);
+  for (int e = t; e < 16 * 16 * 4; e += 256) cnt_s[e] = 0;
+  grp_s[t] = (uint8_t)grp;
+  cols_s[t] = cols;
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int c = (int)(cols >> (4 * q)) & 15;
+      atomicAdd(&cnt_s[(grp * 16 + q) * 4 + (c >> 2)], 1u << (8 * (c & 3)));
+    }
+  }
+  __syncthreads();
+  auto restat = [&](int g, int q) {
+    int M = 0, nM = 0;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const uint32_t v = cnt_s[(g * 16 + q) * 4 + c4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int x = (v >> (8 * b)) & 255;
+        if (x > M) { M = x; nM = 1; } else if (x == M) nM++;
+      }
+    }
+    st_s[g * 16 + q] = (uint16_t)(M | (nM << 8));
+  };
+  if ((t & 15) < NQ) restat(t >> 4, t & 15);
+  __syncthreads();
+  for (int step = 0; step < rounds * 256; step++) {
+    const int r = step & 255;
+    if (r >= nrows) continue;                       // (uniform)
+    const int a = grp_s[r];
+    const unsigned long long ci64 = cols_s[r];
+    const int b = grp;
+    int key = 1 << 30;
+    if (live && b != a) {
+      int d = 0, sec = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int ci = (int)(ci64 >> (4 * q)) & 15, cj = (int)(cols >> (4 * q)) & 15;
+        if (ci != cj) {
+          const int sa = st_s[a * 16 + q], sb = st_s[b * 16 + q];
+          const int Ma = sa & 255, na = sa >> 8, Mb = sb & 255, nb = sb >> 8;
+          const int ca_i = cb[(a * 16 + q) * 16 + ci], ca_j = cb[(a * 16 + q) * 16 + cj];
+          const int cb_i = cb[(b * 16 + q) * 16 + ci], cb_j = cb[(b * 16 + q) * 16 + cj];
+          d += max((ca_i == Ma && na == 1) ? Ma - 1 : Ma, ca_j + 1) - Ma;
+          d += max((cb_j == Mb && nb == 1) ? Mb - 1 : Mb, cb_i + 1) - Mb;
+          sec += (ca_j - ca_i + 1) + (cb_i - cb_j + 1);
+        }
+      }
+      key = d * 2048 + sec;
+    }
+    // the best exchange of row r: minimum of (key, row) over the workgroup
+    int best = ((key + (1 << 20)) << 8) | t;
+    if (key == (1 << 30)) best = 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if (lane == 0) best_s[wave] = best;
+    __syncthreads();
+    best = min(min(best_s[0], best_s[1]), min(best_s[2], best_s[3]));
+    const int bkey = (best >> 8) - (1 << 20);
+    if (!(best == 0x7fffffff || bkey >= 0)) {       // (uniform)
+      const int j = best & 255;
+      const int gb = grp_s[j];
+      const unsigned long long cj64 = cols_s[j];
+      if (t < NQ) {
+        const int q = t;
+        const int ci = (int)(ci64 >> (4 * q)) & 15, cj = (int)(cj64 >> (4 * q)) & 15;
+        if (ci != cj) {
+          cb[(a * 16 + q) * 16 + ci] -= 1; cb[(a * 16 + q) * 16 + cj] += 1;
+          cb[(gb * 16 + q) * 16 + cj] -= 1; cb[(gb * 16 + q) * 16 + ci] += 1;
+          restat(a, q);
+          restat(gb, q);
+        }
+      }
+      __syncthreads();                              // every thread has read grp_s[r], grp_s[j]
+      if (t == r) { grp = gb; grp_s[t] = (uint8_t)gb; }
+      if (t == j) { grp = a; grp_s[t] = (uint8_t)a; }
+    }
+    __syncthreads();
+  }
+  // places: the rows of group g take the lanes of lane group g % 4 in block g / 4, in row order
+  int below = 0;                                    // rows of my group in the waves before mine
+  {
+    for (int g = 0; g < 16; g++) {
+      const unsigned long long mk = __ballot(live && grp == g);
+      if (lane == 0) rank_s[wave][g] = __popcll(mk);
+    }
+    __syncthreads();
+    for (int w2 = 0; w2 < wave; w2++) below += rank_s[w2][grp];
+  }
+  int within = 0;                                   // ... and in my wave, before me
+  for (int g = 0; g < 16; g++) {
+    const unsigned long long mk = __ballot(live && grp == g);
+    if (grp == g) within = __popcll(mk & ((1ull << lane) - 1ull));
+  }
+  if (live) {
+    const long long slot = (wb + (grp >> 2)) * 64 + lds_lane_of_group(grp & 3, below + within);
+    dst[slot] = w;
+    perm[slot] = (uint8_t)t;
+  }
+}
+
 }  // namespace
 
 // codes `src` [nblk][64] 16-byte code words -> `dst` (may not alias src), perm [nblk * 64]
@@ -142,8 +274,18 @@ void launch_conflict_order(const uint8_t *src, uint8_t *dst, uint8_t *perm, long
   const auto s4 = reinterpret_cast<const uint4 *>(src);
   const auto d4 = reinterpret_cast<uint4 *>(dst);
   GULON_REQUIRE(nq == FILTER_LDS_QUANTIZERS, "internal: conflict ordering over %d quantizers", nq);
-  hipLaunchKernelGGL(conflict_order<FILTER_LDS_QUANTIZERS>, grid, dim3(256), 0, st, s4, d4, perm, nblk, rounds);
+  // (GULON_FILTER_ORDER_WINDOW=0: the ordering inside single blocks, for A/B measurements; the copy's readers are told
+  // which one they have through gulon_index::fwindow)
+  if (conflict_order_windowed())
+    hipLaunchKernelGGL(conflict_order_window<FILTER_LDS_QUANTIZERS>, grid, dim3(256), 0, st, s4, d4, perm, nblk, rounds);
+  else
+    hipLaunchKernelGGL(conflict_order<FILTER_LDS_QUANTIZERS>, grid, dim3(256), 0, st, s4, d4, perm, nblk, rounds);
   HIP_CHECK(hipGetLastError());
+}
+
+bool conflict_order_windowed() {
+  static const bool on = [] { const char *e = getenv("GULON_FILTER_ORDER_WINDOW"); return !(e && atoi(e) == 0); }();
+  return on;
 }
 
 }  // namespace gulon

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BOUND_THREADS) void bound_tables(
     const float *__restrict__ cents, const int *__restrict__ from, const int *__restrict__ sdim, int d, int m, int k,
     const float *__restrict__ Q, float *__restrict__ tables, float *__restrict__ mins,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ perm /* codes = the conflict-ordered copy: its row order */,
-    int ng, int m_pad, int row_from, int row_until, int rb_begin, int e_count,
+    int pwin /* blocks per ordering window of that copy - 1 */, int ng, int m_pad, int row_from, int row_until, int rb_begin, int e_count,
     RbMap mp, int B, int keff, float *__restrict__ tau0, float *__restrict__ fin_v, int *__restrict__ fin_i,
     float *__restrict__ bounds_out, unsigned *__restrict__ gtau, int n_gtau, int *__restrict__ fb_tile, int n_fb,
     int *__restrict__ sv_cnt, int n_cnt) {
@@ -393,11 +393,12 @@ __global__ __launch_bounds__(BOUND_THREADS) void bound_tables(
       }
       w = wn;
     }
-    // which row a lane holds only matters in a block the range cuts (the conflict-ordered copy deals a block's rows to
-    // the lanes by `perm`; the sample only needs distances of DISTINCT rows of the range)
+    // which row a lane holds only matters in a window the range cuts (the conflict-ordered copy deals a window's rows to
+    // the lanes of its blocks by `perm`; the sample only needs distances of DISTINCT rows of the range)
     bool valid = true;
-    if (rb * 64 < row_from || rb * 64 + 64 > row_until) {
-      const int row = rb * 64 + (perm ? (int)perm[(size_t)rb * 64 + lane] : lane);
+    const int wrow = (rb & ~pwin) * 64;               // first row of the block's ordering window
+    if (wrow < row_from || wrow + 64 * (pwin + 1) > row_until) {
+      const int row = wrow + (perm ? (int)perm[(size_t)rb * 64 + lane] : lane);
       valid = row >= row_from && row < row_until;
     }
     if (valid) {
@@ -500,7 +501,8 @@ template <int QW, int NQG, int VEC, int NADD, int MAIN,
 __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ perm, int ng, int m_pad, const uint8_t *__restrict__ qtab, int row_from, int row_until,
     int rb_begin, int e_count, int e_per_chunk, RbMap mp, int *__restrict__ cnt, int *__restrict__ queue, int cap /* entries per sub-queue */,
-    const int *__restrict__ fb_tile, int qt, int B) {
+    const int *__restrict__ fb_tile, int qt, int B,
+    int pwin /* ordered copy: blocks per ordering window - 1 (0 or 3) -- `perm` = a row's place in its window */) {
   constexpr int NW = FILTER_THREADS / 64;
   constexpr uint32_t QMAXP = (255u / NADD) * 0x00010001u;   // QMAX in both halves; survive <=> sum <= QMAX - 1
   constexpr int DW = QW / 4;     // dwords per entry
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   // of up front: 3.21, 3.23, 3.36; five 3.96, eight 5.58 -- the L1 path saturates quickly).  It pays only where
   // LDS is the one busy pipe: 16-byte entries, four entries summed per widening, two workgroups per CU (m <= 16);
   // with 4-byte code words, wider indexes (m = 32, 64, 100) or the 7-bit levels it measured 2-50 % slower.
-  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && NADD == 4 && NG1) ? GULON_FILTER_GLB : 0;
+  constexpr int GLB = (QW == 16 && NQG == 1 && VEC == 16 && (NADD == 4 || NADD == 8) && NG1) ? GULON_FILTER_GLB : 0;
   using Word = typename CodeWord<VEC>::type;
   using QE = typename QEntry<QW>::type;
   extern __shared__ uint4 qlds_raw[];
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
   int e_limit = e_count;
   if constexpr (MAIN == 2) {
     const int nflags = (ntile * NQG * QW + 15) & ~15;
-    e_limit = min(e_count, fb_tile[nflags + tile] - rb_begin + 1);
+    e_limit = min(e_count, (fb_tile[nflags + tile] | pwin) - rb_begin + 1);   // (a row sits somewhere in its window)
     if (chunk * e_per_chunk >= e_limit) return;
   }
   // spreads the queue-tail atomics of one query over NSLOT counters
@@ -702,8 +704,9 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       asm volatile("" : "+s"(cnt_l), "+s"(queue_l), "+s"(slot_l), "+s"(tile_l), "+s"(fb_l));
       if (PERM) {
         const uint8_t *perm_l = perm;
-        asm volatile("" : "+s"(perm_l));
-        row = rb * 64 + perm_l[(size_t)rb * 64 + lane];
+        int pwin_l = pwin;
+        asm volatile("" : "+s"(perm_l), "+s"(pwin_l));
+        row = (rb & ~pwin_l) * 64 + perm_l[(size_t)rb * 64 + lane];
         valid = row >= row_from && row < row_until;
       }
 #pragma unroll
@@ -876,7 +879,7 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
   static const size_t lds_pad = getenv("GULON_FILTER_LDS_PAD") ? (size_t)atoi(getenv("GULON_FILTER_LDS_PAD")) : 0;
   const size_t lds_bytes = (size_t)NQG * ix->m_pad * 256 * QW + 16 + (stage == 1 ? lds_pad : 0);   // tables + the run counter
   // (the single-word form only for the instantiation the headline index runs on: m = 16, two workgroups per CU)
-  constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && NADD == 4;
+  constexpr bool one_word_form = QW == 16 && NQG == 1 && VEC == 16 && (NADD == 4 || NADD == 8);
   // stage: 0 a short stage, 1 the main stage (a tag of its own for the profilers), 2 the tie replay's long level
   // (per-tile row limits behind the flags)
 #define GULON_FILTER_PICK(NG1_) \
@@ -912,7 +915,7 @@ void launch_filter_t(gulon_index *ix, int ftiles, int nchunks, int rb_begin, int
 #endif
   hipLaunchKernelGGL(kern, stage == 2 ? dim3(nchunks, ftiles) : dim3(ftiles, nchunks), dim3(FILTER_THREADS), lds_bytes, st, codes, perm, ix->ng, ix->m_pad,
                      ix->qtab.p, from, until, rb_begin, e_count, e_per_chunk, mp, ix->sv_cnt.p, ix->sv_queue.p, cap,
-                     fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B);
+                     fb ? fb : ix->fb_tile.p, fb ? qt : W_fp32 * ix->nsub, B, perm ? ix->fwindow - 1 : 0);
   HIP_CHECK(hipGetLastError());
 #ifdef GULON_FILTER_STAMPS
   if (stage == 1 && stamps_d && getenv("GULON_FILTER_STAMPS")) {
@@ -987,7 +990,11 @@ void launch_filter(gulon_index *ix, int qw, int nqg, int nadd, int ftiles, int n
                    int *fb = nullptr /* tile flags other than the index's own, one per `qt` queries */, int qt = 1) {
 #define GO(W_, Q, V, A) \
   launch_filter_t<W_, Q, V, A>(ix, ftiles, nchunks, rb_begin, e_count, e_per_chunk, mp, from, until, cap, stage, B, st, fb, qt)
+#ifdef GULON_FILTER_NADD8   // experiment builds: 5-bit levels, eight entries per widening (one-word form only)
+#define GO_QV(W_, Q, V) do { if (nadd == 8 && W_ == 16 && Q == 1 && V == 16) GO(16, 1, 16, 8); else if (nadd == 4) GO(W_, Q, V, 4); else GO(W_, Q, V, 2); } while (0)
+#else
 #define GO_QV(W_, Q, V) do { if (nadd == 4) GO(W_, Q, V, 4); else GO(W_, Q, V, 2); } while (0)
+#endif
 #define GO_W(W_) do {                                                  \
     if (ix->vec == 16) { if (nqg == 2) GO_QV(W_, 2, 16); else GO_QV(W_, 1, 16); } \
     else               { if (nqg == 2) GO_QV(W_, 2, 4); else GO_QV(W_, 1, 4); }   \
@@ -1132,6 +1139,23 @@ __global__ __launch_bounds__(256) void rp_filter_emit(const uint8_t *__restrict_
 
 }  // namespace
 
+// The filter launches of an index whose ordered code copy spans windows of several blocks (conflict_order.hip) cover
+// whole windows: a row of [from, until) may sit in any block of its window.  Rows outside the range that come along are
+// rejected one by one where a lane reports a survivor.  Returns the first block and the number of blocks to scan.
+static void filter_block_range(const gulon_index *ix, int qw, int nqg, int nadd, int from, int until, int &rb_begin,
+                               int &rb_total) {
+  rb_begin = from / 64;
+  int rb_end = ceil_div(until, 64);
+  const bool ordered = ix->fcodes.p && ix->ng == 1 && ix->vec == 16 && qw == 16 && nqg == 1 && (nadd == 4 || nadd == 8) &&
+                       tuning_of(ix).filter_order > 0;
+  if (ordered && ix->fwindow > 1) {
+    const int w = ix->fwindow;
+    rb_begin -= rb_begin % w;
+    rb_end = std::min(ceil_div(ix->n, 64), ceil_div(rb_end, w) * w);
+  }
+  rb_total = rb_end - rb_begin;
+}
+
 bool filter_eligible(const gulon_index *ix, int K, int rb_total) {
   const ScanTuning &t = tuning_of(ix);
   return t.filter && !ix->wide && K >= 1 && K <= GULON_MAX_K && (size_t)ix->m_pad * 256 * 4 <= FILTER_LDS_BUDGET &&
@@ -1162,6 +1186,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   const int cap = std::max(64, t.filter_cap / NSLOT);   // entries per sub-queue
   const int rb_begin = from / 64;
   const int rb_total = ceil_div(until, 64) - rb_begin;
+  int frb_begin = rb_begin, frb_total = rb_total;        // what the filter launches scan (whole ordering windows)
+  filter_block_range(ix, qw, nqg, nadd, from, until, frb_begin, frb_total);
   const int P = t.filter_period;
   const int s0 = std::min(std::max(t.filter_stage0, 0), P - 2);
   const int s1 = std::min(std::max(t.filter_stage1, 1), P - 1 - s0);
@@ -1175,7 +1201,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
     // bounds shared by `lists` shards: their union is a sample `lists` times this shard's; once that
     // is about half the rows of the short stages, these stages cost more launches than they save survivors
     // (one rank of 2 / 4 / 8 on the bench index: 1.950 / 1.136 / 0.526 ms with them, 1.944 / 1.074 / 0.496 without)
-    const long long early = ((long long)rbmap_count(rb_total, stages[0]) + rbmap_count(rb_total, stages[1])) * 64;
+    const long long early = ((long long)rbmap_count(frb_total, stages[0]) + rbmap_count(frb_total, stages[1])) * 64;
     const bool keep = t.filter_shared_stage1 < 0 ? 2LL * sb->lists * srows < early : t.filter_shared_stage1 != 0;
     if (!keep) {
       stages[0].width = 0;
@@ -1241,8 +1267,8 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                   \
       hipLaunchKernelGGL(kern, dim3(Bp / W_), dim3(BOUND_THREADS), lds_bytes, st, ix->cents.p, ix->from.p,          \
-                         ix->sdim.p, ix->d, ix->m, ix->k, dQ, ix->tables.p, ix->qmins.p, scodes, sperm, ix->ng,     \
-                         ix->m_pad, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p, ix->fin_i.p, \
+                         ix->sdim.p, ix->d, ix->m, ix->k, dQ, ix->tables.p, ix->qmins.p, scodes, sperm,             \
+                         ordered ? ix->fwindow - 1 : 0, ix->ng, ix->m_pad, from, until, rb_begin, se, smap, B, keff, ix->tau0.p, ix->fin_v.p, ix->fin_i.p, \
                          phase == 1 ? sb->bounds_out : nullptr, ix->gtau.p, Bp, ix->fb_tile.p, ntiles,              \
                          ix->sv_cnt.p, Bq * NSLOT);                                                                 \
     }
@@ -1278,7 +1304,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
   const bool stats = getenv("GULON_FILTER_STATS") != nullptr;
   for (int sidx = 0; sidx < 3; sidx++) {
     const RbMap mp = stages[sidx];
-    const int en = rbmap_count(rb_total, mp);
+    const int en = rbmap_count(frb_total, mp);
     if (en <= 0) continue;
     int nc = 1, per = 1;
     chunking(en, ftiles, t.filter_blocks, nc, per);
@@ -1330,7 +1356,7 @@ void run_filter_query(gulon_index *ix, const float *dQ, int B, int K, int from, 
       if (main_stage && !fresh && turns) HIP_CHECK(hipStreamWaitEvent(st, lane_ev, 0));
       if (timed) HIP_CHECK(hipEventRecord(ev0, st));         // after the wait: the kernel's own duration
       if (!(main_stage && GULON_SKIPPED(16)) && !(!main_stage && GULON_SKIPPED(32)))
-      launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_begin, en, per, mp, from, until, cap, main_stage ? 1 : 0, B, st);
+      launch_filter(ix, qw, nqg, nadd, ftiles, nc, frb_begin, en, per, mp, from, until, cap, main_stage ? 1 : 0, B, st);
       static const int lane_after = getenv("GULON_LANE_AFTER_SURVIVORS") ? atoi(getenv("GULON_LANE_AFTER_SURVIVORS")) : 0;   // experiment knob
       if (main_stage && !lane_after) HIP_CHECK(hipEventRecord(lane_ev, st));
       lane_pending = main_stage && lane_after ? lane_ev : nullptr;
@@ -1414,13 +1440,15 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
                             const int *count, float *evv, int *evi, int *evcnt, int pool, int **only, hipStream_t st,
                             const int *done, const int *rlast, int *scanme /* [F]: written for every flagged slot */) {
   const ScanTuning &t = tuning_of(ix);
-  const int e_count = rb_hi - rb_lo;
+  const int level_from = std::max(from, rb_lo * 64);     // the level's rows: nothing of the earlier levels is emitted again
+  int e_count = rb_hi - rb_lo;
   // (the same conditions as filter_eligible; the byte-code kernels only)
   if (!t.filter || ix->wide || (size_t)ix->m_pad * 256 * 4 > FILTER_LDS_BUDGET || e_count < t.filter_min_rb || K < 1)
     return false;
   const int qw = filter_qw(ix), nqg = filter_nqg(ix);
   const int nadd = t.filter_nadd ? t.filter_nadd : (ix->m_pad <= 16 ? 4 : 2);
   const int qmax = 255 / nadd;
+  filter_block_range(ix, qw, nqg, nadd, rb_lo * 64, std::min(until, rb_hi * 64), rb_lo, e_count);   // whole ordering windows
   const int ftiles = ceil_div(F, qw * nqg);
   const int Fq = ceil_div(ftiles * nqg * qw, 16) * 16;
   const int cap = std::max(64, t.filter_cap / NSLOT);
@@ -1451,7 +1479,7 @@ bool replay_level2_filtered(gulon_index *ix, int F, int K, int rb_lo, int rb_hi,
   const int per = ceil_div(e_count, nc);
   nc = ceil_div(e_count, per);
   const RbMap all{1, 0, 1};
-  launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_lo, e_count, per, all, from, until, cap, 2, F, st, ix->rp_fb.p, 1);
+  launch_filter(ix, qw, nqg, nadd, ftiles, nc, rb_lo, e_count, per, all, level_from, until, cap, 2, F, st, ix->rp_fb.p, 1);
   if (ix->vec == 16)
     hipLaunchKernelGGL(rp_filter_emit<16>, dim3(F), dim3(256), 0, st, ix->codes.p, ix->ng, ix->m_pad, tables, ix->row_base,
                        ix->sv_cnt.p, ix->sv_queue.p, cap, count, F, ix->rp_tau.p, ix->rp_fb.p, evv, evi, evcnt, pool,

@@ -649,7 +649,7 @@ bool ScanTuning::set(const char *key, int v) {
   else if (k == "GULON_FILTER_PERIOD") { if (v >= 3) filter_period = v; }
   else if (k == "GULON_FILTER_STAGE1") { if (v >= 1) filter_stage1 = v; }
   else if (k == "GULON_FILTER_CAP") { if (v >= 64) filter_cap = v; }
-  else if (k == "GULON_FILTER_NADD") { if (v == 0 || v == 2 || v == 4) filter_nadd = v; }
+  else if (k == "GULON_FILTER_NADD") { if (v == 0 || v == 2 || v == 4 || v == 8) filter_nadd = v; }   // (8: experiment builds only)
   else if (k == "GULON_FILTER_SAMPLE") { if (v >= 1) filter_sample = v; }
   else if (k == "GULON_FILTER_STAGE0") { if (v >= 0) filter_stage0 = v; }
   else if (k == "GULON_FILTER_BLOCKS") { if (v >= 1) filter_blocks = v; }
@@ -713,7 +713,8 @@ void launch_scan_p(gulon_index *ix, int ntiles, int nchunks, int rb_begin, int e
                                 (int)lds_bytes));
   // one-word codes: the exact scan's table gathers are the same ds_read_b128 of 256 x 16-byte entries per quantizer as
   // the filter's, so the conflict-ordered copy serves it too (13 of its 16 quantizers were ordered for)
-  const bool ordered = VEC == 16 && ix->ng == 1 && ix->fcodes.p && tuning_of(ix).filter_order > 0;
+  // (the exact scan walks row blocks one at a time: it reads the ordered copy only where a block holds its own rows)
+  const bool ordered = VEC == 16 && ix->ng == 1 && ix->fcodes.p && ix->fwindow == 1 && tuning_of(ix).filter_order > 0;
   hipLaunchKernelGGL(kern, dim3(ntiles, nchunks), dim3(SCAN_THREADS), lds_bytes, st, ordered ? ix->fcodes.p : ix->codes.p,
                      ix->ng, ix->m_pad,
                      reinterpret_cast<const float4 *>(ix->tables.p), from, until, ix->row_base, rb_begin, e_count,
@@ -1022,6 +1023,7 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
         ix->fcodes.alloc(nblk * 1024);
         ix->fperm.alloc(nblk * 64);
         launch_conflict_order(ix->codes.p, ix->fcodes.p, ix->fperm.p, (long long)nblk, FILTER_LDS_QUANTIZERS, rounds, 0);
+        ix->fwindow = conflict_order_windowed() ? 4 : 1;
         HIP_CHECK(hipDeviceSynchronize());
       }
     }
@@ -1041,6 +1043,7 @@ gulon_index *make_context(gulon_index *parent) {
   c->codes.borrow(parent->codes);
   c->fcodes.borrow(parent->fcodes);
   c->fperm.borrow(parent->fperm);
+  c->fwindow = parent->fwindow;
   c->wcodes.borrow(parent->wcodes);
   c->cents.borrow(parent->cents);
   c->from.borrow(parent->from);

@@ -36,6 +36,7 @@ struct gulon_index {
   // the filter's own copy of one-word codes (m <= 16), rows re-dealt inside every 64-row block for the LDS bank
   // conflicts of its table gathers (conflict_order.hip), and each lane's place in the block's row order
   DevBuf<uint8_t> fcodes, fperm;   // [n/64][64][16], [n/64][64]
+  int fwindow = 1;                 // blocks per ordering window of fcodes (4: fperm = place in a 256-row window; 1: in the block)
   bool wide = false;       // k > 256: 16-bit codes, tables in HBM (wide.hip)
   DevBuf<uint16_t> wcodes; // wide: [n/64][m][64]
   DevBuf<float> wpartial;  // wide, sliced tables: running sums [queries of the sub-batch][rows]
@@ -249,4 +250,5 @@ void run_tie_replay(gulon_index *ix, const float *dQ, int B, int K, int from, in
                     int *d_oc, int *d_of, hipStream_t st);
 void launch_conflict_order(const uint8_t *src, uint8_t *dst, uint8_t *perm, long long nblk, int nq, int rounds,
                            hipStream_t st);
+bool conflict_order_windowed();   // the ordering spans windows of four blocks (default) or single blocks
 }  // namespace gulon

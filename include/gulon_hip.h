@@ -141,11 +141,12 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
  * for every divisor n in [1, n_max] (n_max < 2^24) and `numerators_per_divisor` numerators each (random, and
  * next to rounding boundaries).  *mismatches must come back 0. */
 int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed, int64_t *mismatches);
-/* Self-test of the filter's conflict-ordered code copy (conflict_order.hip; no reference counterpart: the order of
- * the rows inside a 64-row block of the device copy is an implementation detail behind PQIndex.batchQuery,
- * Index.scala:209-263).  codes: n_blocks x 64 rows x 16 code bytes; codes_out receives the re-dealt blocks,
- * place_out[b * 64 + lane] the row (0..63) of block b that now sits in `lane`.  Every block of place_out must be a
- * permutation and codes_out[b][lane] == codes[b][place_out[b][lane]]; rounds = passes of the ordering (0: identity). */
+/* Self-test of the filter's conflict-ordered code copy (conflict_order.hip; no reference counterpart: where a row
+ * sits inside the device copy is an implementation detail behind PQIndex.batchQuery, Index.scala:209-263).
+ * codes: n_blocks x 64 rows x 16 code bytes; rows are re-dealt inside WINDOWS of four consecutive blocks (a last
+ * window of fewer blocks: inside the blocks it has).  codes_out receives the re-dealt blocks, place_out[b * 64 + lane]
+ * the place (0..255) in its window of the row that now sits in `lane` of block b: over a window the places are a
+ * permutation and codes_out[b][lane] == codes[window rows][place].  rounds = passes of the ordering (0: identity). */
 int32_t gulon_selftest_conflict_order(const uint8_t *codes, int64_t n_blocks, int32_t rounds, uint8_t *codes_out,
                                       uint8_t *place_out);
 /* Self-test of the bf16-split MFMA filter of KMeans.assign (kmeans_mfma.hip, assign_bf16): largest
