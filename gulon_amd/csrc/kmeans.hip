@@ -681,6 +681,8 @@ __global__ void mean_division_selftest(int n_max, int per, unsigned long long se
     unsigned long long z = seed + (unsigned long long)w * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
     const float nf = (float)n;
+    // the reciprocal the streamed update computes in its loop (kmeans_stream.hip): every divisor it is used for
+    if (e == 0 && __float_as_uint(rcp_rn_int(nf)) != __float_as_uint(__fdiv_rn(1.0f, nf))) mism++;
     // a random float with exponent in [-40, 40]
     const unsigned mant = (unsigned)(z & 0x7FFFFF), sgn = (unsigned)((z >> 23) & 1);
     const int ex = (int)((z >> 24) % 81) - 40;
@@ -696,6 +698,18 @@ __global__ void mean_division_selftest(int n_max, int per, unsigned long long se
     const float fast = mean_quotient_fast(a, nf, y);
     const float ref = __fdiv_rn(a, nf);
     if (__float_as_uint(fast) != __float_as_uint(ref)) mism++;
+  }
+  // the divisors 2^j - 1 (the integers nearest to the all-ones significands the proofs single out): EVERY numerator
+  // significand and sign of one binade -- the arithmetic is scale invariant between the under- and overflow ranges
+  // the callers keep out of -- with the reciprocal of the streamed update (tests/test_markstein_exhaustive.py is the
+  // same sweep on the CPU)
+  for (long long w = t; w < (24ll << 24); w += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(w >> 24) + 1;
+    if ((1 << j) - 1 > n_max) break;
+    const float nf = (float)((1 << j) - 1);
+    const float a = __uint_as_float((((unsigned)w >> 23) & 1u) << 31 | 127u << 23 | ((unsigned)w & 0x7FFFFFu));
+    const float fast = mean_quotient_fast(a, nf, rcp_rn_int(nf));
+    if (__float_as_uint(fast) != __float_as_uint(__fdiv_rn(a, nf))) mism++;
   }
   if (mism) atomicAdd(bad, mism);
 }
@@ -1355,6 +1369,10 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     unsigned *h_mism = nullptr;
     PackedSlice packed;      // MFMA-ready copy of this problem's column slice
     DevBuf<float> xs;        // row-major n x s copy of the slice: compact target of the update's gathers
+    // the streamed update (kmeans_stream.hip): the slice pair-major, and per-update scratch (chunk-local order, offsets)
+    DevBuf<float> xp;
+    DevBuf<unsigned short> s_ord, s_coff;
+    DevBuf<int> s_wild;
     AssignJob job;
     bool use_mfma = false;
     bool done = false;
@@ -1405,6 +1423,9 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
   };
 
   DevBuf<UpdDesc> d_descs(np);
+  DevBuf<StreamDesc> d_sdescs(np);
+  bool stream_update = true;     // every problem through kmeans_stream.hip (all or none: one batched launch pair)
+  for (int p = 0; p < np; p++) stream_update = stream_update && stream_update_supported(n, k, sdim[p]);
   hipStream_t bst = nullptr;
   hipEvent_t upd_done = nullptr;
   HIP_CHECK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
@@ -1445,6 +1466,17 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     // the matrix-core operands from the COMPACT copy: the strided slices of the row-major data cost a partial line per
     // row and pass (pack_slice_split 1.0 ms per sub-quantizer at BASELINE config 3 from the rows, 0.3 from the copy)
     if (pr.use_mfma) pack_slice(pr.xs.p, n, s, 0, s, k, pr.packed, pr.st);
+    if (stream_update) {
+      const size_t ns = (size_t)stream_padded_rows(n);
+      pr.xp.alloc(2 * ns * (size_t)((s + 1) / 2));
+      HIP_CHECK(hipMemsetAsync(pr.xp.p, 0, sizeof(float) * 2 * ns * (size_t)((s + 1) / 2), pr.st));   // the padding rows
+      pr.s_wild.alloc(1);
+      HIP_CHECK(hipMemsetAsync(pr.s_wild.p, 0, sizeof(int), pr.st));
+      stream_pack_pairs(pr.xs.p, n, s, pr.xp.p, pr.s_wild.p, pr.st);
+      size_t coff_words = 0;
+      pr.s_ord.alloc(stream_order_words(n, k, &coff_words));
+      pr.s_coff.alloc(coff_words);
+    }
     make_job(p, pr.c_prev.p, pr.a_prev.p);
     assign_stage1(pr.job);
     push_report(p, gulon_kmeans_report{0, 0, 0, 0.f, 0.f});
@@ -1471,10 +1503,21 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     // assign under the next chains, so that the first assign starts after a quarter of the update: 12 iterations at
     // BASELINE config 3 take 0.66 s with one group, 0.71 / 0.79 / 0.93 s with 2 / 4 / 8 -- the memory-bound regrouping
     // and the assign slow each other down by more than the overlap saves.)
-    std::vector<UpdDesc> descs;
-    for (int p : act)
-      descs.push_back(make_upd_desc(P[p].ws, P[p].xs.p, sdim[p], n, k, 0, sdim[p], P[p].a_prev.p, P[p].c_next.p));
-    kmeans_update_batch(descs, d_descs.p, n, k, bst);
+    if (stream_update) {
+      std::vector<StreamDesc> sd;
+      for (int p : act) {
+        StreamDesc D{};
+        D.assign = P[p].a_prev.p; D.xp = P[p].xp.p; D.ord = P[p].s_ord.p; D.coff = P[p].s_coff.p; D.cout = P[p].c_next.p; D.wild = P[p].s_wild.p;
+        D.s = sdim[p]; D.ns = stream_padded_rows(n);
+        sd.push_back(D);
+      }
+      kmeans_update_stream(sd, d_sdescs.p, n, k, bst);   // (sd is read by hipMemcpyAsync from pageable memory: staged before the call returns)
+    } else {
+      std::vector<UpdDesc> descs;
+      for (int p : act)
+        descs.push_back(make_upd_desc(P[p].ws, P[p].xs.p, sdim[p], n, k, 0, sdim[p], P[p].a_prev.p, P[p].c_next.p));
+      kmeans_update_batch(descs, d_descs.p, n, k, bst);
+    }
     HIP_CHECK(hipEventRecord(upd_done, bst));
     lap("  update batch", &tt.update_ms);
     for (int p : act) {

@@ -106,6 +106,34 @@ void assign_stage3(AssignJob &j);
 // exact re-check of the flagged rows; without it every row takes the exact VALU kernel.
 void kmeans_assign_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, const float *dC, int k,
                        int rng_batch, int *d_assign, hipStream_t st, const PackedSlice *ps = nullptr);
+#ifdef __HIPCC__
+// RN(1 / n) for an integer n < 2^24 whose significand is not all ones: the hardware reciprocal (1 ulp) and one
+// fma-corrected Newton step (Markstein).  Checked against 1.0f / n for EVERY such n by gulon_selftest_mean_division.
+__device__ __forceinline__ float rcp_rn_int(float nf) {
+  const float y0 = __builtin_amdgcn_rcpf(nf);
+  const float e = __builtin_fmaf(-nf, y0, 1.0f);
+  return __builtin_fmaf(e, y0, y0);
+}
+#endif
+
+// kmeans_stream.hip: KMeans.fromAssignment from a pair-major copy of the slices, read once in row order
+struct StreamDesc {
+  const int *assign;        // [n]
+  const float *xp;          // pair-major slice: [pairs][ns] float2, pair j = dimensions (2j, 2j + 1)
+  unsigned short *ord;      // scratch: [chunks][STREAM_CH] local row indices, stable by cluster
+  unsigned short *coff;     // scratch: [chunks][k + 1] first position of every cluster in its chunk
+  float *cout;              // k x s centroids out
+  const int *wild;          // nonzero: the slice holds values the corrected quotient is not trusted with (stream_pack_pairs)
+  int s, pad;
+  long long ns;             // rows per pair in xp = stream_padded_rows(n): whole chunks, the padding zeroed
+};
+bool stream_update_supported(int n, int k, int s);
+size_t stream_order_words(int n, int k, size_t *coff_words);
+long long stream_padded_rows(int n);   // rows per pair of the pair-major copy (whole chunks, zero padded)
+void stream_pack_pairs(const float *xs, int n, int s, float *xp /* [pairs][ns] float2 */, int *wild /* zeroed; set if any |x| >= 2^99, infinite or NaN */,
+                       hipStream_t st);
+void kmeans_update_stream(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st);
+
 // kmeans_fused.hip: KMeans.fromAssignment without the regrouped copy (false: the shape keeps the bucketed path)
 bool kmeans_update_fused(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st);
 void kmeans_update_dev(KmeansWorkspace &ws, const float *dX, int n, int ld, int from, int s, int k,
