@@ -15,7 +15,7 @@ HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.
 # dropped fused k-means update (kmeans_fused.hip) live in a second library that only tests/ loads: the same objects,
 # with the four files that have hooks compiled again under -DGULON_TEST_HOOKS.
 HOOKLIB = gulon_amd/lib/libgulon_hip_testhooks.so
-HOOKED = kmeans kmeans_mfma conflict_order kmeans_fused
+HOOKED = kmeans kmeans_stream kmeans_mfma conflict_order kmeans_fused
 HOOKOBJS = $(patsubst %,$(OBJDIR)/%.hooks.o,$(HOOKED)) $(filter-out $(patsubst %,$(OBJDIR)/%.o,$(HOOKED)),$(OBJS))
 
 all: $(LIB) $(HOOKLIB) oracle build/test_host_api

@@ -11,21 +11,24 @@
 //   * per update, stream_order computes for every chunk of CH rows the stable order of its rows by cluster (ord[row] =
 //     the row's POSITION in that order, 2 bytes per row) and where each cluster's rows start in it (coff) -- the
 //     counting sort of sort_place without the data;
-//   * stream_chains: ONE workgroup per (sub-quantizer, dimension pair), thread = cluster.  It walks the chunks in order:
-//     the chunk's 8-byte values are staged in LDS AT THEIR POSITIONS in the chunk's stable order (the next chunk's values
-//     and positions are requested before the current one's chain steps and land in registers meanwhile), and every
-//     thread applies the rows of ITS cluster -- consecutive LDS entries -- to the pair of running means it keeps in
-//     registers.  Row order inside a cluster is the chunks' order followed by
-//     the stable order inside a chunk: the reference's.
+//   * stream_chains: ONE workgroup per (sub-quantizer, dimension pair): chain threads (thread = cluster) and loader
+//     threads.  It walks the chunks in order: the loader waves write the chunk's 8-byte values to LDS AT THEIR POSITIONS
+//     in the chunk's stable order, one chunk ahead of the chain waves (and request the chunk after that meanwhile), and
+//     every chain thread applies the rows of ITS cluster -- consecutive LDS entries -- to the pair of running means it
+//     keeps in registers.  Row order inside a cluster is the chunks' order followed by the stable order inside a chunk:
+//     the reference's.
 //
 // Per step the arithmetic is update_chains_pk's: a = x - c, the correctly rounded quotient a / n as the corrected
-// product with y = RN(1 / n) (mean_quotient_fast, kmeans.hip) -- y is computed in the loop, off the dependent chain
-// (n is known long before c is): v_rcp_f32 and one fma-corrected Newton step, which IS the correctly rounded reciprocal
-// for every integer n < 2^24 whose significand is not all ones (checked exhaustively against 1.0f / n by
-// gulon_selftest_mean_division) -- and the plain division where the corrected form is not trusted (tiny / huge / zero /
-// NaN numerators, divisors with all-ones significands).
+// product with y = RN(1 / n) (mean_quotient_fast, kmeans.hip) -- y is computed a group of four steps ahead (n is known
+// long before c is): v_rcp_f32 and one fma-corrected Newton step, which IS the correctly rounded reciprocal for every
+// integer n < 2^24 (checked exhaustively against 1.0f / n by gulon_selftest_mean_division) -- and the plain division
+// where the corrected form is not trusted: numerators below 2^-100 (found per chunk, which is then redone), values of
+// 2^99 and beyond / infinities / NaNs anywhere in the slice (found when it is packed), counts from 2^24.
 // Traffic per update: the pair-major data once (12.8 GB) + order and offsets (2 bytes per row and pair workgroup,
 // mostly served by L2: the pair workgroups of a sub-quantizer walk the same chunks at the same pace).
+// BASELINE config 3 (10 M x 300, 32 sub-quantizers, k = 256), per update: stream_order 1.0 ms + stream_chains 3.6 ms
+// against 9.3-10.2 ms; the chain kernel's time is its longest chain's: rows of the largest cluster of a wave x 15
+// instructions per step x the 7-8 cycles a lone wave needs per instruction.
 #include "kmeans.hpp"
 
 namespace gulon {
@@ -126,11 +129,6 @@ __global__ __launch_bounds__(256) void stream_order(const StreamDesc *__restrict
     if (valid && (same[t] & lt) == 0ull) wh[wave * k + key] = b + (unsigned)__popcll(same[t]);
     ord[lr] = valid ? (unsigned short)pos : (unsigned short)STREAM_CH;   // (a padding row of the last chunk: not staged)
   }
-}
-
-__device__ __forceinline__ bool fast_ok(float a) {
-  const float m = fabsf(a);
-  return m > 8.673617379884035e-19f /* 2^-60 */ && m < 1.152921504606847e18f /* 2^60 */;
 }
 
 // T chain threads = clusters (k <= T) and L loader threads; one workgroup per (dimension pair, sub-quantizer).
@@ -257,10 +255,17 @@ __global__ __launch_bounds__(T + L) void stream_chains(const StreamDesc *__restr
     for (int u = 0; u < 4; u++) xn[u] = dat[ib + u];
     const f32x2 nA2 = nA + 4.0f, nB2 = nB + 4.0f;
     const f32x2 yA2 = recip2(nA2), yB2 = recip2(nB2);
-    if (i < ce) step(x[0], -__builtin_shufflevector(nA, nA, 0, 0), __builtin_shufflevector(yA, yA, 0, 0));
-    if (i + 1 < ce) step(x[1], -__builtin_shufflevector(nA, nA, 1, 1), __builtin_shufflevector(yA, yA, 1, 1));
-    if (i + 2 < ce) step(x[2], -__builtin_shufflevector(nB, nB, 0, 0), __builtin_shufflevector(yB, yB, 0, 0));
-    if (i + 3 < ce) step(x[3], -__builtin_shufflevector(nB, nB, 1, 1), __builtin_shufflevector(yB, yB, 1, 1));
+    const int left = ce - i;                           // (nested: the lanes of a step are a subset of the previous step's)
+    if (left > 0) {
+      step(x[0], -__builtin_shufflevector(nA, nA, 0, 0), __builtin_shufflevector(yA, yA, 0, 0));
+      if (left > 1) {
+        step(x[1], -__builtin_shufflevector(nA, nA, 1, 1), __builtin_shufflevector(yA, yA, 1, 1));
+        if (left > 2) {
+          step(x[2], -__builtin_shufflevector(nB, nB, 0, 0), __builtin_shufflevector(yB, yB, 0, 0));
+          if (left > 3) step(x[3], -__builtin_shufflevector(nB, nB, 1, 1), __builtin_shufflevector(yB, yB, 1, 1));
+        }
+      }
+    }
     nA = nA2; nB = nB2; yA = yA2; yB = yB2;
   };
   // chunk t: its values are in dat_s[t & 1]; register slot t % RING is free (stashed one chunk ago) and takes chunk
@@ -401,3 +406,37 @@ void kmeans_update_stream(const std::vector<StreamDesc> &descs, StreamDesc *d_de
 }
 
 }  // namespace gulon
+
+#ifdef GULON_TEST_HOOKS
+using namespace gulon;
+// KMeans.fromAssignment (KMeans.scala:198-226) of ONE slice through the streamed update, whatever the caller's shape
+// (tests/test_gpu_kmeans.py: the library proper takes this path inside PQ training only)
+GULON_API int32_t gulon_selftest_stream_update(const float *x, int32_t n, int32_t ld, int32_t from, int32_t s, int32_t k,
+                                               const int32_t *assign, float *centroids_out) {
+  return guarded([&] {
+    GULON_REQUIRE(x && assign && centroids_out && n >= 1 && s >= 1 && from >= 0 && from + s <= ld, "bad arguments");
+    GULON_REQUIRE(stream_update_supported(n, k, s), "shape not supported by the streamed update");
+    std::vector<float> slice((size_t)n * s);
+    for (int r = 0; r < n; r++) memcpy(&slice[(size_t)r * s], x + (size_t)r * ld + from, sizeof(float) * s);
+    DevBuf<float> xs((size_t)n * s), cout((size_t)k * s);
+    DevBuf<int> a(n), wild(1);
+    const size_t ns = (size_t)stream_padded_rows(n);
+    DevBuf<float> xp(2 * ns * (size_t)((s + 1) / 2));
+    size_t coff_words = 0;
+    DevBuf<unsigned short> ord(stream_order_words(n, k, &coff_words)), coff(coff_words);
+    DevBuf<StreamDesc> d_desc(1);
+    HIP_CHECK(hipMemcpy(xs.p, slice.data(), sizeof(float) * slice.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(a.p, assign, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(wild.p, 0, sizeof(int)));
+    HIP_CHECK(hipMemset(xp.p, 0, sizeof(float) * 2 * ns * (size_t)((s + 1) / 2)));
+    HIP_CHECK(hipMemset(cout.p, 0, sizeof(float) * (size_t)k * s));
+    stream_pack_pairs(xs.p, n, s, xp.p, wild.p, 0);
+    StreamDesc D;
+    D.assign = a.p; D.xp = xp.p; D.ord = ord.p; D.coff = coff.p; D.cout = cout.p; D.wild = wild.p;
+    D.s = s; D.pad = 0; D.ns = (long long)ns;
+    kmeans_update_stream({D}, d_desc.p, n, k, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(centroids_out, cout.p, sizeof(float) * (size_t)k * s, hipMemcpyDeviceToHost));
+  });
+}
+#endif

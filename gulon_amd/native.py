@@ -131,6 +131,7 @@ _lib = None
 HOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libgulon_hip_testhooks.so")
 TEST_HOOK_SIGNATURES = {
     "gulon_selftest_mean_division": (_i32, [_i32, _i32, C.c_uint64, C.POINTER(C.c_int64)]),
+    "gulon_selftest_stream_update": (_i32, [C.c_void_p, _i32, _i32, _i32, _i32, _i32, C.c_void_p, C.c_void_p]),
     "gulon_selftest_conflict_order": (_i32, [C.c_void_p, C.c_int64, _i32, C.c_void_p, C.c_void_p]),
     "gulon_selftest_assign_band": (_i32, [_i32, C.c_uint64, C.c_float, C.POINTER(C.c_double)]),
 }

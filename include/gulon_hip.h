@@ -141,6 +141,11 @@ int32_t gulon_kmeans_train(const gulon_dataset *ds, int32_t from, int32_t s, int
  * for every divisor n in [1, n_max] (n_max < 2^24) and `numerators_per_divisor` numerators each (random, and
  * next to rounding boundaries).  *mismatches must come back 0. */
 int32_t gulon_selftest_mean_division(int32_t n_max, int32_t numerators_per_divisor, uint64_t seed, int64_t *mismatches);
+/* KMeans.fromAssignment (KMeans.scala:198-226) of one slice -- columns [from, from + s) of the host matrix x (n rows,
+ * leading dimension ld), host assignments in [0, k) -- through the STREAMED update of PQ training (kmeans_stream.hip),
+ * which the library proper reaches inside gulon_pq_train only.  centroids_out: k x s. */
+int32_t gulon_selftest_stream_update(const float *x, int32_t n, int32_t ld, int32_t from, int32_t s, int32_t k,
+                                     const int32_t *assign, float *centroids_out);
 /* Self-test of the filter's conflict-ordered code copy (conflict_order.hip; no reference counterpart: where a row
  * sits inside the device copy is an implementation detail behind PQIndex.batchQuery, Index.scala:209-263).
  * codes: n_blocks x 64 rows x 16 code bytes; rows are re-dealt inside WINDOWS of four consecutive blocks (a last

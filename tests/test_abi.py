@@ -44,7 +44,7 @@ def test_product_library_carries_no_test_hooks():
     """Self-tests and the dropped fused-update experiment are in libgulon_hip_testhooks.so only."""
     from gulon_amd import native
     hooks = _header_symbols(hooks=True)
-    assert hooks == sorted(native.TEST_HOOK_SIGNATURES) and len(hooks) == 3
+    assert hooks == sorted(native.TEST_HOOK_SIGNATURES) and len(hooks) == 4
     def exported(path):
         out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
         return {l.split()[-1] for l in out.splitlines() if " T " in l}

@@ -188,6 +188,62 @@ def test_mean_division_identity_holds_for_every_divisor(g):
     assert bad.value == 0
 
 
+def _stream_update(g, X, frm, s, k, a):
+    out = np.zeros((k, s), np.float32)
+    X = np.ascontiguousarray(X, np.float32)
+    a = np.ascontiguousarray(a, np.int32)
+    rc = g.native.hooks_lib().gulon_selftest_stream_update(X.ctypes.data, X.shape[0], X.shape[1], frm, s, k, a.ctypes.data,
+                                                           out.ctypes.data)
+    assert rc == 0, g.native.hooks_lib().gulon_last_error()
+    return out
+
+
+@pytest.mark.parametrize("n,d,frm,s,k,kind", [
+    (100, 4, 0, 4, 7, "plain"),                 # less than one chunk
+    (8192, 5, 0, 5, 256, "plain"),              # exactly one chunk, an odd last dimension
+    (3 * 8192 + 5, 7, 2, 3, 200, "plain"),      # a ragged last chunk
+    (40000, 6, 1, 1, 33, "plain"),              # one dimension (paired with itself)
+    (50000, 8, 0, 8, 300, "plain"),             # 257..512 clusters: 512 chain threads
+    (50000, 4, 0, 4, 700, "plain"),             # 513..1024 clusters: the chain threads move the chunks themselves
+    (30000, 6, 0, 6, 1024, "plain"),
+    (40000, 6, 0, 6, 64, "skewed"),             # one cluster holds most rows; some hold none
+    (40000, 6, 0, 6, 40, "zeros"),              # sparse rows and duplicates: zero numerators all the way
+    (40000, 6, 0, 6, 40, "tiny"),               # denormal and near-denormal values: the plain division's chunks
+    (40000, 6, 0, 6, 40, "huge"),               # 2^99 and beyond, infinities, NaNs: every chunk by plain division
+])
+def test_streamed_update_edge_cases(oracle, g, n, d, frm, s, k, kind):
+    """KMeans.fromAssignment (KMeans.scala:198-226) through the streamed update of PQ training: chunk boundaries, the
+    three workgroup shapes, and the data the corrected quotient is not trusted with (which must take the plain division
+    and still come out bit-identical)."""
+    rng = np.random.default_rng(n + k)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    a = rng.integers(0, k, n).astype(np.int32)
+    if kind == "skewed":
+        a = np.where(rng.random(n) < 0.8, 3, rng.integers(0, k // 2, n)).astype(np.int32)
+    elif kind == "zeros":
+        X[rng.random((n, d)) < 0.7] = 0.0
+        X[::3] = X[0]
+    elif kind == "tiny":
+        m = rng.random((n, d))
+        X[m < 0.05] *= np.float32(1e-38)
+        X[(m >= 0.05) & (m < 0.1)] *= np.float32(1e-44)
+        X[(m >= 0.1) & (m < 0.15)] *= np.float32(1e-33)
+    elif kind == "huge":
+        m = rng.random((n, d))
+        X[m < 0.02] *= np.float32(3e37)
+        X[(m >= 0.02) & (m < 0.03)] *= np.float32(1e30)
+        X[5000, frm] = np.inf
+        X[9000, frm + 1] = -np.inf
+        X[12000, frm + 2] = np.nan
+    with np.errstate(all="ignore"):
+        want = oracle.kmeans_from_assignment(X, frm, s, k, a)
+    got = _stream_update(g, X, frm, s, k, a)
+    # NaNs compare by position (payloads are not part of the contract: a JVM canonicalises them)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(bits(got)[ok], bits(want)[ok])
+
+
 @pytest.mark.parametrize("n,d,frm,s,k", [(60000, 6, 1, 3, 12000), (80000, 4, 0, 4, 40000)])
 def test_more_than_10240_clusters(oracle, g, n, d, frm, s, k):
     """ProductQuantizer.coderFactory allows up to 65 536 clusters per quantizer (ProductQuantizer.scala:11-16):
