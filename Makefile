@@ -8,9 +8,9 @@ OBJDIR = build/obj
 LIB = gulon_amd/lib/libgulon_hip.so
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
            -fvisibility=hidden -Wall -Wno-unused-function -Iinclude
-SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip $(CSRC)/kmeans_stream.hip $(CSRC)/kmeans_mfma.hip $(CSRC)/replay.hip $(CSRC)/filter.hip $(CSRC)/grouped.hip $(CSRC)/wide.hip $(CSRC)/wide_filter.hip $(CSRC)/conflict_order.hip $(CSRC)/sharded.hip $(CSRC)/literal.hip
+SRCS = $(CSRC)/api_core.hip $(CSRC)/scan.hip $(CSRC)/knn.hip $(CSRC)/kmeans.hip $(CSRC)/kmeans_stream.hip $(CSRC)/kmeans_mfma.hip $(CSRC)/replay.hip $(CSRC)/filter.hip $(CSRC)/grouped.hip $(CSRC)/grouped_filter.hip $(CSRC)/wide.hip $(CSRC)/wide_filter.hip $(CSRC)/conflict_order.hip $(CSRC)/sharded.hip $(CSRC)/literal.hip
 OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
-HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.h
+HDRS = $(CSRC)/common.hpp $(CSRC)/scan.hpp $(CSRC)/kmeans.hpp include/gulon_hip.h $(CSRC)/grouped_filter.hpp
 # The product library carries no test code.  The self-tests of three kernels (gulon_selftest_*) and the measured-and-
 # dropped fused k-means update (kmeans_fused.hip) live in a second library that only tests/ loads: the same objects,
 # with the four files that have hooks compiled again under -DGULON_TEST_HOOKS.

@@ -23,6 +23,7 @@
 //                       reference's also under ties (GULON_GROUPED_LITERAL=1: every query).
 #include "scan.hpp"
 
+#include "grouped_filter.hpp"
 using gulon::DevBuf;
 
 struct gulon_grouped_index {
@@ -38,6 +39,7 @@ struct gulon_grouped_index {
   // approximate pre-selection (gq_approx_scan): |g + decode(codes_i)|^2 per row, its maximum, per-query tables, lists
   DevBuf<float> xnorm, ptab, apv, amv;
   DevBuf<int> api, ami, anan;
+  gulon::GroupFilter gfilter;     // the same pre-selection batched by group with 8-bit bound tables (grouped_filter.hip)
   float xnmax = 0.f;
   int n_empty = 0;                 // groups without rows (the reference's leading empty group, WordVectors.scala:38-39)
   std::mutex mu;
@@ -101,17 +103,28 @@ struct RegHeap {
 // ---- coarse search: distances of every query to every group centroid -------------------------
 // MathUtils.distanceSq(centroid, query): sum of (q_e - c_e)^2, e ascending, unfused.
 // gcent_t is the [d][g] transpose: consecutive threads (centroids) read consecutive addresses.
+// A thread takes one centroid and CD_Q queries: the centroid's coordinates are read once for all of them (one query
+// per thread re-read the 5 MB of centroids per query: 5 GB through L2 per batch, 0.33 ms at 10 001 groups).
+constexpr int CD_Q = 8;
 __global__ __launch_bounds__(256) void gq_cdist(const float *__restrict__ gcent_t, int g, int d,
                                                 const float *__restrict__ Q, int B, float *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, q0 = blockIdx.y * CD_Q;
   if (c >= g) return;
-  const float *y = Q + (size_t)q * d;
-  float sum = 0.f;
+  const int nq = min(CD_Q, B - q0);
+  float sum[CD_Q];
+#pragma unroll
+  for (int i = 0; i < CD_Q; i++) sum[i] = 0.f;
   for (int e = 0; e < d; e++) {
-    const float dx = y[e] - gcent_t[(size_t)e * g + c];
-    sum += dx * dx;
+    const float ce = gcent_t[(size_t)e * g + c];
+#pragma unroll
+    for (int i = 0; i < CD_Q; i++) {
+      const float dx = Q[(size_t)(q0 + min(i, nq - 1)) * d + e] - ce;     // (wave-uniform address: a scalar load)
+      sum[i] += dx * dx;
+    }
   }
-  out[(size_t)q * g + c] = sum;
+#pragma unroll
+  for (int i = 0; i < CD_Q; i++)
+    if (i < nq) out[(size_t)(q0 + i) * g + c] = sum[i];
 }
 
 // LimitGroups(limit <= 63): literal exactNearestNeighbours(centroids, query, limit).deleteAll()
@@ -851,7 +864,9 @@ __global__ __launch_bounds__(64 * GA_WAVES) void gq_approx_scan(const uint8_t *_
                                                                 const float *__restrict__ gcent,
                                                                 const int *__restrict__ bounds, const float *__restrict__ Q,
                                                                 const int *__restrict__ nn, int nn_stride,
-                                                                const int *__restrict__ nn_cnt, float *__restrict__ lv,
+                                                                const int *__restrict__ nn_cnt, int gmax /* searched groups taken at most */,
+                                                                int split /* waves that share a group's row blocks (1, 2, 4 ..) */,
+                                                                float *__restrict__ lv,
                                                                 int *__restrict__ li, int *__restrict__ nanflag) {
   using Word = typename CodeWord<VEC>::type;
   extern __shared__ float ga_lds[];           // m_pad * 256 table entries, then d query coordinates
@@ -867,9 +882,9 @@ __global__ __launch_bounds__(64 * GA_WAVES) void gq_approx_scan(const uint8_t *_
   WaveList wl;
   wl.init();
   int cnt = 0, saw_nan = 0;
-  const int ngroups = nn_cnt[q];
+  const int ngroups = min(nn_cnt[q], gmax);
   const Word *cw = reinterpret_cast<const Word *>(codes);
-  for (int t = wave; t < ngroups; t += GA_WAVES) {
+  for (int t = wave / split; t < ngroups; t += GA_WAVES / split) {
     const int c = nn[(size_t)q * nn_stride + t];
     const int row_from = bounds[c], row_until = bounds[c + 1];
     float qg = 0.f;
@@ -877,12 +892,12 @@ __global__ __launch_bounds__(64 * GA_WAVES) void gq_approx_scan(const uint8_t *_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) qg += __shfl_xor(qg, o);
     const float base = qq - 2.0f * qg;
-    const int rb_first = row_from >> 6, rb_end = (row_until + 63) >> 6;
+    const int rb_first = (row_from >> 6) + wave % split, rb_end = (row_until + 63) >> 6;
     Word wnext{};
     if (rb_first < rb_end) wnext = cw[((size_t)rb_first * ng) * 64 + lane];
-    for (int rb = rb_first; rb < rb_end; rb++) {
+    for (int rb = rb_first; rb < rb_end; rb += split) {
       const Word w0 = wnext;
-      if (rb + 1 < rb_end) wnext = cw[((size_t)(rb + 1) * ng) * 64 + lane];
+      if (rb + split < rb_end) wnext = cw[((size_t)(rb + split) * ng) * 64 + lane];
       const int row = rb * 64 + lane;
       const bool valid = row >= row_from && row < row_until;
       float acc = base + (valid ? xnorm[row] : 0.f);
@@ -1105,7 +1120,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   gx->cdist.ensure((size_t)B * g);
   gx->nn.ensure((size_t)B * nn_stride);
   gx->nn_cnt.ensure((size_t)B);
-  hipLaunchKernelGGL(gq_cdist, dim3(ceil_div(g, 256), B), dim3(256), 0, st, gx->gcent_t.p, g, gx->d, dQ, B,
+  hipLaunchKernelGGL(gq_cdist, dim3(ceil_div(g, 256), ceil_div(B, CD_Q)), dim3(256), 0, st, gx->gcent_t.p, g, gx->d, dQ, B,
                      gx->cdist.p);
   if (strategy == 0 && limit <= GULON_MAX_K && limit >= 1) {
     hipLaunchKernelGGL(gq_nearest_groups, dim3(B), dim3(64), 0, st, gx->cdist.p, g, limit, gx->nn.p, nn_stride,
@@ -1241,9 +1256,26 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       auto kern = ix->vec == 16 ? gq_approx_scan<16> : gq_approx_scan<4>;
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_ga));
+      // by group with 8-bit bound tables (grouped_filter.hip): the threshold of every query from the rows of its nearest
+      // groups, then the filter; else every searched row through this kernel
+      // the nearest groups whose rows give a query its threshold: the fewest (a power of two up to 16) that hold ~1000 rows
+      static const int sample_env = [] { const char *e = getenv("GULON_GROUPED_SAMPLE"); return e ? atoi(e) : 0; }();
+      int sample_groups = 1;
+      while (sample_groups < GF_SAMPLE_GROUPS && (long long)sample_groups * gx->n < 1024ll * g) sample_groups <<= 1;
+      if (sample_env == 1 || sample_env == 2 || sample_env == 4 || sample_env == 8 || sample_env == 16) sample_groups = sample_env;
+      const bool by_group = gx->gfilter.built && group_filter_applies(ix->m, ix->m_pad, ix->ng, ix->vec, ix->k, ix->d) &&
+                            nn_stride > GF_SAMPLE_GROUPS;
       hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GA_WAVES), lds_ga, st, ix->codes.p, ix->ng, ix->m_pad, ix->d, gx->ptab.p,
-                         gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p, gx->apv.p,
-                         gx->api.p, gx->anan.p);
+                         gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p,
+                         by_group ? sample_groups : INT_MAX, by_group ? GA_WAVES / sample_groups : 1, gx->apv.p, gx->api.p,
+                         gx->anan.p);
+      if (by_group) {
+        launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
+                     nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
+        group_filter_run(gx->gfilter, ix->codes.p, ix->ng, ix->vec, ix->m, ix->m_pad, ix->k, ix->d, gx->ptab.p, gx->xnorm.p, gx->xnmax,
+                         gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->amv.p, gx->apv.p, gx->api.p,
+                         gx->anan.p, st);
+      }
     }
     launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
                  nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
@@ -1415,6 +1447,8 @@ GULON_API int32_t gulon_grouped_index_create(const uint8_t *codes, int32_t n, in
       unsigned h = 0;
       HIP_CHECK(hipMemcpy(&h, mx.p, sizeof(h), hipMemcpyDeviceToHost));
       memcpy(&gx->xnmax, &h, sizeof(float));
+      if (gx->xnmax < INFINITY && group_filter_applies(pq->m, pq->m_pad, pq->ng, pq->vec, pq->k, d))
+        group_filter_build(gx->gfilter, gx->xnorm.p, n, gx->gcent.p, gx->bounds.p, g, d);
     }
     *out = gx.release();
   });

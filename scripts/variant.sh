@@ -11,7 +11,7 @@ for stem in ${stems//,/ }; do
 done
 wait
 objs=""
-for f in api_core scan knn kmeans kmeans_stream kmeans_mfma replay filter grouped wide wide_filter conflict_order sharded literal; do
+for f in api_core scan knn kmeans kmeans_stream kmeans_mfma replay filter grouped grouped_filter wide wide_filter conflict_order sharded literal; do
   if [[ ",$stems," == *",$f,"* ]]; then objs="$objs build/expt/${f}_$tag.o"; else objs="$objs build/obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/expt/libgulon_$tag.so $objs -ldl

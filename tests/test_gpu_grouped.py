@@ -140,6 +140,35 @@ def test_bad_arguments(g):
     assert N.lib().gulon_grouped_index_create(codes, 10, 8, 4, 256, cents, gc, off, 2, C.byref(h)) == -1
 
 
+@pytest.mark.parametrize("n,d,groups,m,k,limit,dup,bad_query", [
+    (120000, 32, 400, 16, 256, 120, 0, False),     # the regime it is built for: many groups, m = 16
+    (60000, 24, 300, 8, 64, 90, 3000, False),      # duplicated rows: equal D~ at the cut, ties in the re-ranking
+    (60000, 16, 250, 4, 16, 250, 0, True),         # every group searched; a NaN query and a far-away query
+])
+def test_by_group_filter_equals_reference(oracle, g, monkeypatch, capfd, n, d, groups, m, k, limit, dup, bad_query):
+    """GroupedIndex.query (Index.scala:265-299) through the by-group pre-selection with 8-bit bound tables
+    (grouped_filter.hip): it only chooses which rows are re-scored with the reference's arithmetic, so the answers must
+    be the reference's; the statistics line shows that the path ran."""
+    monkeypatch.setenv("GULON_GROUPED_STATS", "1")
+    B, K = 40, 10
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + groups, dup=dup, iters=2)
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    index = g.Index.grouped(gv, pq, g.LimitGroups(limit))
+    rng = np.random.default_rng(5)
+    Q = np.concatenate([X[rng.integers(0, n, B - 2)], (rng.standard_normal((2, d)) * 3).astype(np.float32)])
+    if bad_query:
+        Q[3, 1] = np.nan
+        Q[4] *= np.float32(1e4)
+    oi, od, oc = index.batch_query_raw(K, Q)
+    assert "by-group filter" in capfd.readouterr().err
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, 0, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist(), q
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]])), q
+    index.close()
+
+
 @pytest.mark.parametrize("dup", [0, 2000])
 def test_many_groups_radix_select_of_the_nearest(oracle, g, dup):
     """LimitGroups(70) of ~300 groups: the nearest groups come from the radix-select kernel
