@@ -100,6 +100,58 @@ struct RegHeap {
   }
 };
 
+// TopKHeap.scala for k_nn > 63: the arrays in LDS (one heap per wave).  Every lane runs the same wave-uniform code
+// and reads the same entries; lane 0 stores.  (LDS operations of a wave execute in order.)  A fallback: Tests.scala
+// asks for up to 1000 neighbours, the benchmarks for 10.
+struct LdsHeap {
+  volatile float *hv;
+  volatile int *hk;
+  int size = 0;
+  int cap;
+  int lane;
+  __device__ LdsHeap(float *v_, int *k_, int cap_, int lane_) : hv(v_), hk(k_), cap(cap_), lane(lane_) {}
+  __device__ float val(int i) const { return hv[i]; }
+  __device__ int key(int i) const { return hk[i]; }
+  __device__ void put(int i, int kk, float x) { if (lane == 0) { hv[i] = x; hk[i] = kk; } }
+  __device__ void swp(int a, int b) {
+    const float va = val(a), vb = val(b);
+    const int ka = key(a), kb = key(b);
+    put(a, kb, vb);
+    put(b, ka, va);
+  }
+  __device__ void down(int i) {                             // percolateDown, TopKHeap.scala:30-42
+    for (;;) {
+      int top = i;
+      const int lc = 2 * i + 1, rc = 2 * i + 2;
+      if (lc < size && val(top) < val(lc)) top = lc;
+      if (rc < size && val(top) < val(rc)) top = rc;
+      if (top == i) break;
+      swp(i, top);
+      i = top;
+    }
+  }
+  __device__ int del() {                                    // delete, TopKHeap.scala:57-67
+    size -= 1;
+    const int removed = key(0);
+    put(0, key(size), val(size));
+    down(0);
+    return removed;
+  }
+  __device__ bool would_insert(float x) const { return size < cap || val(0) > x; }
+  __device__ void update(int kk, float x) {                 // update, TopKHeap.scala:69-79
+    if (size == cap && val(0) > x) del();
+    if (size < cap) {
+      put(size, kk, x);
+      int i = size;
+      while (i > 0) {                                       // percolateUp, TopKHeap.scala:21-28
+        const int p = (i - 1) / 2;
+        if (val(i) > val(p)) { swp(i, p); i = p; } else break;
+      }
+      size += 1;
+    }
+  }
+};
+
 // ---- coarse search: distances of every query to every group centroid -------------------------
 // MathUtils.distanceSq(centroid, query): sum of (q_e - c_e)^2, e ascending, unfused.
 // gcent_t is the [d][g] transpose: consecutive threads (centroids) read consecutive addresses.
@@ -397,7 +449,7 @@ __global__ __launch_bounds__(64) void gq_literal_groups(const float *__restrict_
 constexpr int GQ_WAVES = 4;    // (query, group) pairs per workgroup: they share the staged codebook slices
 constexpr int GQ_RPT = 8;      // centroid components prefetched per thread (sub-vectors up to 8 wide are fully overlapped)
 constexpr int GQ_PD = 4;       // quantizers whose codebooks are in flight
-template <int VEC, bool LITERAL>
+template <int VEC, bool LITERAL, bool BIG = false /* k_nn > 63: the literal heap in LDS */>
 __global__ __launch_bounds__(64 * GQ_WAVES) void gq_group_scan(const uint8_t *__restrict__ codes, int ng, int m, int m_pad, int k,
                                                     int d, const float *__restrict__ pq_cents,
                                                     const int *__restrict__ from, const int *__restrict__ sdim,
@@ -473,7 +525,14 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void gq_group_scan(const uint8_t *__
   if (!live) continue;
   const int row_from = bounds[c], row_until = bounds[c + 1];
   const int keff = K + 1;
-  RegHeap h(K, lane);
+  // (BIG: the heaps sit behind the tables and the codebook slice)
+  float *bigv = gq_lds + (size_t)GQ_WAVES * (m_pad * 256 + d) + slice_floats + (size_t)wave * (BIG ? K : 0);
+  int *bigk = reinterpret_cast<int *>(gq_lds + (size_t)GQ_WAVES * (m_pad * 256 + d) + slice_floats + (size_t)GQ_WAVES * (BIG ? K : 0)) +
+              (size_t)wave * (BIG ? K : 0);
+  typename std::conditional<BIG, LdsHeap, RegHeap>::type h = [&] {
+    if constexpr (BIG) return LdsHeap(bigv, bigk, K, lane);
+    else return RegHeap(K, lane);
+  }();
   WaveList wl;
   wl.init();
   int cnt = 0, saw_nan = 0;
@@ -527,7 +586,11 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void gq_group_scan(const uint8_t *__
   }
   if (LITERAL) {
     const size_t o = ((size_t)q * stride + t) * K;
-    if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
+    if constexpr (BIG) {
+      for (int i = lane; i < h.size; i += 64) { hk[o + i] = h.key(i); hv[o + i] = h.val(i); }
+    } else {
+      if (lane < h.size) { hk[o + lane] = h.k; hv[o + lane] = h.v; }
+    }
     if (lane == 0) hs[(size_t)q * stride + t] = h.size;
   } else {
     const size_t o = ((size_t)q * stride + t) * keff;
@@ -1008,23 +1071,32 @@ __global__ __launch_bounds__(64) void gq_rerank(const uint8_t *__restrict__ code
 }
 
 // ---- TopKHeap.merge of the group heaps in search order, Result.fromHeap ---------------------------
+template <bool BIG>
 __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const float *__restrict__ hv,
                                                const int *__restrict__ hs, const int *__restrict__ nn_cnt, int stride,
                                                int K, int *__restrict__ out_idx, float *__restrict__ out_dist,
                                                int *__restrict__ out_count, const int *__restrict__ qlist,
                                                const int *__restrict__ qcount) {
+  extern __shared__ float gm_lds[];            // BIG: K values, then K keys
   const int lane = threadIdx.x;
   const int nq = qlist ? *qcount : (int)gridDim.x;
   for (int fx = blockIdx.x; fx < nq; fx += gridDim.x) {
   const int q = qlist ? qlist[fx] : fx;
-  RegHeap h(K, lane);
+  typename std::conditional<BIG, LdsHeap, RegHeap>::type h = [&] {
+    if constexpr (BIG) return LdsHeap(gm_lds, reinterpret_cast<int *>(gm_lds + K), K, lane);
+    else return RegHeap(K, lane);
+  }();
   const int cnt = nn_cnt[q];
   for (int t = 0; t < cnt; t++) {
     const size_t o = ((size_t)q * stride + t) * K;
     const int sz = hs[(size_t)q * stride + t];
-    const int kk = lane < sz ? hk[o + lane] : 0;
-    const float vv = lane < sz ? hv[o + lane] : 0.f;
-    for (int i = 0; i < sz; i++) h.update(readlane_i(kk, i), readlane_f(vv, i));   // array order
+    if constexpr (BIG) {
+      for (int i = 0; i < sz; i++) h.update(hk[o + i], hv[o + i]);                    // array order
+    } else {
+      const int kk = lane < sz ? hk[o + lane] : 0;
+      const float vv = lane < sz ? hv[o + lane] : 0.f;
+      for (int i = 0; i < sz; i++) h.update(readlane_i(kk, i), readlane_f(vv, i));   // array order
+    }
   }
   const int live = h.size;
   for (int i = live - 1; i >= 0; i--) {                     // Result.fromHeap: max first, fill from the back
@@ -1032,7 +1104,7 @@ __global__ __launch_bounds__(64) void gq_merge(const int *__restrict__ hk, const
     const int tk = h.del();
     if (lane == 0) { out_idx[(size_t)q * K + i] = tk; out_dist[(size_t)q * K + i] = tv; }
   }
-  if (lane >= live && lane < K) { out_idx[(size_t)q * K + lane] = -1; out_dist[(size_t)q * K + lane] = INFINITY; }
+  for (int i = live + lane; i < K; i += 64) { out_idx[(size_t)q * K + i] = -1; out_dist[(size_t)q * K + i] = INFINITY; }
   if (lane == 0 && out_count) out_count[q] = live;
   }
 }
@@ -1103,11 +1175,27 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   GULON_REQUIRE(B >= 0 && K >= 0, "k and batch size must be non-negative");
   GULON_REQUIRE(strategy == 0 || strategy == 1, "strategy must be 0 (LimitGroups) or 1 (LimitVectors)");
   GULON_REQUIRE(limit >= 0, "limit must be non-negative");
-  GULON_UNSUPPORTED(K > GULON_MAX_K, "k_nn = %d > GULON_MAX_K = %d is not supported by the grouped index", K,
-                    GULON_MAX_K);
+  // k_nn > GULON_MAX_K (Tests.scala asks for up to 1000): the literal kernels with the heaps in LDS, for every query
+  constexpr int GROUPED_MAX_K_BIG = 2048;
+  const bool big_k = K > GULON_MAX_K;
+  GULON_UNSUPPORTED(K > GROUPED_MAX_K_BIG, "k_nn = %d > %d is not supported by the grouped index", K, GROUPED_MAX_K_BIG);
   if (B == 0) return;
   gulon_index *ix = gx->pq;
   const int g = gx->g;
+  GULON_UNSUPPORTED(big_k && ix->wide, "k_nn = %d > GULON_MAX_K = %d is not supported by a grouped index with 16-bit codes", K,
+                    GULON_MAX_K);
+  if (big_k) {   // the per-group heaps are B x groups x k_nn entries: batches of queries that keep them under 2 GiB
+    const long long per_query = (long long)std::max(1, std::min(strategy == 1 ? g : limit, g)) * K;
+    const int sub = (int)std::max<long long>(1, std::min<long long>(B, (1ll << 28) / std::max<long long>(1, per_query)));
+    if (sub < B) {
+      for (int q0 = 0; q0 < B; q0 += sub) {
+        const int nb = std::min(sub, B - q0);
+        run_grouped_query(gx, dQ + (size_t)q0 * gx->d, nb, K, strategy, limit, d_oi + (size_t)q0 * K, d_od + (size_t)q0 * K,
+                          d_oc ? d_oc + q0 : nullptr, st);
+      }
+      return;
+    }
+  }
   if (K == 0) {
     if (d_oc) HIP_CHECK(hipMemsetAsync(d_oc, 0, sizeof(int) * (size_t)B, st));
     return;
@@ -1160,7 +1248,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
                            limit, gx->lit_flag.p, 2, (const int *)nullptr, (const int *)nullptr, gx->nn.p, nn_stride,
                            gx->nn_cnt.p);
         lit_cap = hcap;
-        if (ix->wide || getenv("GULON_GROUPED_LITERAL") != nullptr) {
+        if (ix->wide || big_k || getenv("GULON_GROUPED_LITERAL") != nullptr) {
           // every query's result comes from the literal heaps, merged in search order: the order-only ties as well
           hipLaunchKernelGGL(gq_literal_groups, dim3(B), dim3(64), hl, st, gx->cdist.p, g, hcap, gx->bounds.p, strategy == 1,
                              limit, gx->lit_flag.p, 1, (const int *)nullptr, (const int *)nullptr, gx->nn.p, nn_stride,
@@ -1196,12 +1284,12 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     hipLaunchKernelGGL(gq_group_scan_wide, dim3(blocks), dim3(64), sizeof(float) * (size_t)ix->d, st, ix->wcodes.p, ix->m,
                        ix->k, ix->d, ix->cents.p, ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride,
                        gx->nn_cnt.p, stride, B, K, gx->wide_tables.p, gx->hk.p, gx->hv.p, gx->hs.p);
-    hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+    hipLaunchKernelGGL(gq_merge<false>, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
                        d_od, d_oc, (const int *)nullptr, (const int *)nullptr);
     HIP_CHECK(hipGetLastError());
     return;
   }
-  const bool literal_only = getenv("GULON_GROUPED_LITERAL") != nullptr;   // testing aid: literal kernels for every query
+  const bool literal_only = big_k || getenv("GULON_GROUPED_LITERAL") != nullptr;   // (the variable: a testing aid)
   gx->hk.ensure((size_t)B * stride * keff);
   gx->hv.ensure((size_t)B * stride * keff);
   gx->hs.ensure((size_t)B * stride);
@@ -1214,12 +1302,15 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     for (int j = 0; j < ix->m; j++) smax = std::max(smax, un[j] - fr[j]);
   }
   const int slice_floats = 256 * smax;               // [x][256], transposed
-  const size_t lds = ((size_t)GQ_WAVES * (ix->m_pad * 256 + ix->d) + (size_t)slice_floats) * sizeof(float);
-  GULON_UNSUPPORTED(lds > 160 * 1024, "grouped query needs %zu B of LDS (m = %d, d = %d)", lds, ix->m, ix->d);
+  const size_t lds = ((size_t)GQ_WAVES * (ix->m_pad * 256 + ix->d) + (size_t)slice_floats + (big_k ? (size_t)GQ_WAVES * 2 * K : 0)) *
+                     sizeof(float);
+  GULON_UNSUPPORTED(lds > 160 * 1024, "grouped query needs %zu B of LDS (m = %d, d = %d, k_nn = %d)", lds, ix->m, ix->d, K);
   auto scan = [&](bool literal, int gy, const int *qlist, const int *qcount) {
-#define GS(V, L)                                                                                                    \
+#define GS3(V) GS_(V, true, true)
+#define GS(V, L) GS_(V, L, false)
+#define GS_(V, L, BG)                                                                                               \
     {                                                                                                               \
-      auto kern = gq_group_scan<V, L>;                                                                              \
+      auto kern = gq_group_scan<V, L, BG>;                                                                             \
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
       hipLaunchKernelGGL(kern, dim3(ceil_div(stride, GQ_WAVES), gy), dim3(64 * GQ_WAVES), lds, st, ix->codes.p, ix->ng, \
@@ -1228,14 +1319,20 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
                          nn_stride, gx->nn_cnt.p, stride, K, gx->hk.p, gx->hv.p, gx->hs.p, qlist, qcount,          \
                          slice_floats);                                                                            \
     }
-    if (ix->vec == 16) { if (literal) GS(16, true) else GS(16, false) }
+    if (big_k) { if (ix->vec == 16) GS3(16) else GS3(4) }
+    else if (ix->vec == 16) { if (literal) GS(16, true) else GS(16, false) }
     else               { if (literal) GS(4, true) else GS(4, false) }
 #undef GS
+#undef GS3
     HIP_CHECK(hipGetLastError());
   };
   if (literal_only) {
     scan(true, B, nullptr, nullptr);
-    hipLaunchKernelGGL(gq_merge, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+    if (big_k)
+      hipLaunchKernelGGL(gq_merge<true>, dim3(B), dim3(64), sizeof(float) * 2 * (size_t)K, st, gx->hk.p, gx->hv.p, gx->hs.p,
+                         gx->nn_cnt.p, stride, K, d_oi, d_od, d_oc, (const int *)nullptr, (const int *)nullptr);
+    else
+    hipLaunchKernelGGL(gq_merge<false>, dim3(B), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
                        d_od, d_oc, (const int *)nullptr, (const int *)nullptr);
     HIP_CHECK(hipGetLastError());
     return;
@@ -1297,7 +1394,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     }
     const int fy = std::min(B, 16);
     scan(true, fy, gx->qlist.p, gx->qcount.p);
-    hipLaunchKernelGGL(gq_merge, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+    hipLaunchKernelGGL(gq_merge<false>, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
                        d_od, d_oc, gx->qlist.p, gx->qcount.p);
     HIP_CHECK(hipGetLastError());
     return;
@@ -1366,7 +1463,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
   }
   const int fy = std::min(B, 16);
   scan(true, fy, gx->qlist.p, gx->qcount.p);
-  hipLaunchKernelGGL(gq_merge, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
+  hipLaunchKernelGGL(gq_merge<false>, dim3(fy), dim3(64), 0, st, gx->hk.p, gx->hv.p, gx->hs.p, gx->nn_cnt.p, stride, K, d_oi,
                      d_od, d_oc, gx->qlist.p, gx->qcount.p);
   HIP_CHECK(hipGetLastError());
 }

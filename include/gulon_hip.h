@@ -331,7 +331,8 @@ int32_t gulon_sharded_index_info(const gulon_sharded_index *idx, int32_t *n_shar
  * equally distant coarse centroids included (they are common: WordVectors.grouped's leading empty
  * group repeats a centroid, WordVectors.scala:38-39): queries whose searched groups hang on such a tie
  * (or on a NaN distance) select their groups through the literal exactNearestNeighbours heap.
- * Groups may be empty (offsets may repeat).  k_nn <= GULON_MAX_K. */
+ * Groups may be empty (offsets may repeat).  k_nn <= GULON_MAX_K on the fast paths; up to 2048 (8-bit codes) through
+ * the literal heaps alone, kept in LDS (Tests.scala asks for up to 1000 neighbours). */
 typedef struct gulon_grouped_index gulon_grouped_index;
 int32_t gulon_dataset_group_residuals(const gulon_dataset *ds, const int32_t *perm, const int32_t *group_of,
                                       const float *group_centroids, int32_t g, gulon_dataset **out);

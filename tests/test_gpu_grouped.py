@@ -169,6 +169,32 @@ def test_by_group_filter_equals_reference(oracle, g, monkeypatch, capfd, n, d, g
     index.close()
 
 
+@pytest.mark.parametrize("n,d,groups,m,k,strategy,limit,K,dup", [
+    (6000, 16, 12, 4, 16, "groups", 5, 64, 0),          # just past the wavefront heaps
+    (20000, 32, 40, 16, 256, "groups", 12, 100, 0),
+    (8000, 24, 10, 6, 64, "vectors", 3000, 200, 1500),  # duplicated rows: the heaps' array order decides
+    (3000, 8, 6, 2, 8, "groups", 6, 1000, 0),           # Tests.scala's largest k; groups smaller than k
+])
+def test_more_than_63_neighbours(oracle, g, n, d, groups, m, k, strategy, limit, K, dup):
+    """GroupedIndex.query with k > 63 (Tests.scala samples k up to 1000): the literal TopKHeaps with their arrays in LDS,
+    merged in search order (Index.scala:265-299, TopKHeap.scala)."""
+    B = 6
+    X, dm, coarse, gv, pq = _build(oracle, g, n, d, groups, m, k, seed=n + K, dup=dup)
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    strat = g.LimitGroups(limit) if strategy == "groups" else g.LimitVectors(limit)
+    index = g.Index.grouped(gv, pq, strat)
+    rng = np.random.default_rng(9)
+    Q = np.concatenate([X[rng.integers(0, n, B - 1)], (rng.standard_normal((1, d)) * 2).astype(np.float32)])
+    oi, od, oc = index.batch_query_raw(K, Q)
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K,
+                                      0 if strategy == "groups" else 1, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist(), q
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]])), q
+    index.close()
+
+
 @pytest.mark.parametrize("dup", [0, 2000])
 def test_many_groups_radix_select_of_the_nearest(oracle, g, dup):
     """LimitGroups(70) of ~300 groups: the nearest groups come from the radix-select kernel
