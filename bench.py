@@ -150,12 +150,12 @@ def extras(args, g, N, L, torch, dev, HipEngine, ShardedIndex, local_shard, reca
                         "rows_rechecked_exactly": tot.rows_rechecked / max(tot.rows_total, 1.0)},
         "update": {"bound": "hbm", "achieved": u_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u_gb / HBM_PEAK_GBS,
                    "bytes_per_iteration": tot.update_bytes / it,
-                   # what the update actually moves: the slices are read, written regrouped by cluster (row stride
-                   # rounded up to even) and read again by the chains
+                   # what the streamed update moves: per sub-quantizer the pair-major slice once (8 bytes per
+                   # row and dimension pair), the assignments (4 bytes per row), the chunk order written and read (2 + 2)
                    "physical": (lambda moved: {"bytes_moved_per_iteration": moved,
                                                "GB_per_s": moved / (tot.update_ms / it * 1e-3) / 1e9 if tot.update_ms > 0 else 0.0,
                                                "frac": moved / (tot.update_ms / it * 1e-3) / 1e9 / HBM_PEAK_GBS if tot.update_ms > 0 else 0.0})(
-                       4.0 * c3n * sum(s_ + 2 * ((s_ + 1) & ~1) for s_ in
+                       1.0 * c3n * sum(8 * ((s_ + 1) // 2) + 8 for s_ in
                                        [c3d // c3m + (1 if j < c3d % c3m else 0) for j in range(c3m)]))}}
     note("extras: C3 k-means")
     return ex

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 profiles, collected on the GPU box into gpurun_out/r03/ (summaries are copied to profiles/r03/):
-#   scripts/collect_profiles_r03.sh [part ...]     parts: bench pmc exact shard forms kmeans kind1 other
+#   scripts/collect_profiles_r03.sh [part ...]     parts: bench pmc exact shard forms kmeans kind1 other grouped
 # Every rocprofv3 invocation has the python program directly after `--`; counters in passes of their own
 # (FETCH_SIZE and WRITE_SIZE never share a pass), never together with tracing other than --kernel-trace.
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -61,11 +61,11 @@ forms)
   ;;
 kmeans)
   GULON_KMEANS_SERIAL=1 stats kmeans_c3 python3 $root/scripts/bench_kmeans.py 10000000 300 32 2
-  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
     n=pmc_kmeans_$(echo $grp | tr ' ' '_' | cut -c1-30)
     GULON_KMEANS_SERIAL=1 pmc $n "$grp" python3 $root/scripts/bench_kmeans.py 10000000 300 32 1
   done
-  (cd "$root" && for k in assign_bf16 update_chains sort_place; do python3 scripts/pmc_summary.py "$k" $out/pmc_kmeans_* > "$out/kmeans_c3_${k}_pmc.csv"; done)
+  (cd "$root" && for k in assign_bf16 stream_chains stream_order; do python3 scripts/pmc_summary.py "$k" $out/pmc_kmeans_* > "$out/kmeans_c3_${k}_pmc.csv"; done)
   cat "$out/kmeans_c3_assign_bf16_pmc.csv"
   (cd "$root" && GULON_TRACE=1 python3 scripts/bench_kmeans.py 10000000 300 32 2 > "$out/kmeans_c3_trace.txt" 2>&1); tail -16 "$out/kmeans_c3_trace.txt"
   find "$out" -path "*pmc_kmeans_*" -name '*counter_collection.csv' -size +8M -delete
@@ -76,6 +76,9 @@ kind1)
 other)
   (cd "$root" && python3 tests/perf/bench_grouped.py 10000000 2>/dev/null | tail -1 > "$out/bench_grouped_10M.json"; python3 tests/perf/bench_grouped.py 1000000 2>/dev/null | tail -1 > "$out/bench_grouped_1M.json"
    python3 tests/perf/bench_wide.py 2>/dev/null | tail -1 > "$out/bench_wide_1M_k1024.json"; python3 tests/perf/bench_wide.py 1000000 4096 2>/dev/null | tail -1 > "$out/bench_wide_1M_k4096.json")
+  ;;
+grouped)
+  stats grouped_10M python3 $root/tests/perf/bench_grouped.py 10000000
   ;;
 esac; done
 echo done
