@@ -522,6 +522,10 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     //           ONE exchange per tile and block tells the upper half where the lower half left the running minimum;
     //   pass 2  every lane scans its 16 keys in order from the state it now knows: the minimum before the block for
     //           the lower half, min(that, the lower half's 16) for the upper half.
+    // (Not replaceable by "smallest and second smallest within the band": the reference draws a random bit at EVERY exact
+    // tie of its scan, also at one that a later, smaller distance makes irrelevant for this row -- and the draw moves the
+    // stream the later rows of the 25 000-row batch break their ties with.  A running (min, second) per lane -- two
+    // instructions per key, no exchanges -- was built and fails test_init_assign_update_bit_exact for exactly that.)
     // Running minimum and the centroid it sits at are the same in both lanes of a row afterwards; the band distance
     // accumulates per lane and the two are combined once per tile pair.  A key carries its register number (4 bits:
     // 15 ulp of perturbation instead of 31); which half a block's minimum came from is read off the two minima.
