@@ -30,7 +30,13 @@ namespace gulon {
 constexpr int RP_MAXF = 1024;    // flagged queries replayed per batch (all of a 1024-query batch)
 constexpr int RP_POOL = 8192;    // candidate rows kept per flagged query (more: the flagged result stays)
 constexpr int RP_LDS_POOL = 16384;   // candidates rp_heap can sort in LDS (all shards of a query together)
-constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = 2048, RP_L1_SEG = 64, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
+#ifndef GULON_RP_L1_BLOCKS
+#define GULON_RP_L1_BLOCKS 2048
+#endif
+#ifndef GULON_RP_L1_SEG
+#define GULON_RP_L1_SEG 64
+#endif
+constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = GULON_RP_L1_BLOCKS, RP_L1_SEG = GULON_RP_L1_SEG, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
 
 // Candidate buffer ("pack", int32 words) for F flagged queries with C candidates each:
 //   [0] flagged queries in this pack (<= F)   [1] F   [2] C   [3] flagged queries of the whole batch
