@@ -19,7 +19,7 @@
 //
 // Nothing here is the reference's arithmetic; it only decides which 64 rows are re-scored with it, and it must not lose
 // a row whose D~ is among the 64 smallest.  Every rounding goes the safe way: levels are rounded down (and saturate at
-// 63, which alone exceeds any budget), budgets are rounded up, the threshold is raised by gq_rerank's error margin (the
+// 127, which alone exceeds any budget), budgets are rounded up, the threshold is raised by gq_rerank's error margin (the
 // distance between a computed D~ and its real-number value), and a query whose inputs are not finite, whose threshold
 // is missing (fewer than 64 rows) or whose survivors overflow their queue keeps everything / is flagged for the
 // literal kernels.
@@ -34,7 +34,12 @@ constexpr int GF_THREADS = 512;
 constexpr int GF_NW = GF_THREADS / 64;
 constexpr int GF_NT = 17;                       // tables per query: 16 quantizers and the row norm
 constexpr float GF_SHRINK = 0.99999905f;        // 1 - 2^-20: a product of two roundings stays below the real product
-constexpr float GF_LEVELS = 60.0f;              // the largest budget in steps (63 = saturated; two steps of slack)
+#ifndef GULON_GF_NADD
+#define GULON_GF_NADD 1
+#endif
+constexpr int GF_NADD = GULON_GF_NADD;          // table entries summed as bytes before a widening: 4 (6-bit levels), 2 (7-bit) or 1 (8-bit)
+constexpr int GF_SAT = 255 / GF_NADD;           // a saturated level: alone it exceeds any budget (63 / 127 / 255)
+constexpr float GF_LEVELS = (float)(GF_SAT - 3); // the largest budget in steps (two steps of slack below saturation)
 
 __device__ inline uint32_t gf_pk_sub_sat_u16(uint32_t a, uint32_t b) {   // per 16-bit half: max(a - b, 0)
   uint32_t d;
@@ -234,9 +239,9 @@ __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int
   for (int e = tid; e < GF_NT * 256; e += 256) {
     const int j = e >> 8, c = e & 255;
     int lv = 0;
-    if (j < m && c < k) lv = min(63, max(0, (int)((Pq[j * 256 + c] - s_lo[j]) * invs)));
-    else if (j == 16) lv = min(63, max(0, (int)(((float)c * xn_step) * invs)));
-    else if (j < m) lv = 63;
+    if (j < m && c < k) lv = min(GF_SAT, max(0, (int)((Pq[j * 256 + c] - s_lo[j]) * invs)));
+    else if (j == 16) lv = min(GF_SAT, max(0, (int)(((float)c * xn_step) * invs)));
+    else if (j < m) lv = GF_SAT;
     out[e] = (uint8_t)lv;
   }
 }
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(GF_THREADS) void gf_filter(const uint8_t *__restric
       const float base = qq - 2.0f * qg;
       int lim;                                 // a row survives with a level sum below lim
       if (i >= nq) lim = 0;
-      else if (n_inv[h2] == 0.f) lim = 63;
+      else if (n_inv[h2] == 0.f) lim = GF_SAT;
       else {
         const float f = floorf((n_bud[h2] - (base + n_xl)) * n_inv[h2]);
-        lim = f >= 62.f ? 63 : f >= -1.f ? (int)f + 2 : 0;    // (steps rounded down) + 1 for the rounding, + 1: "below"
+        lim = f >= (float)(GF_SAT - 1) ? GF_SAT : f >= -1.f ? (int)f + 2 : 0;   // (steps rounded down) + 1 for the rounding, + 1: "below"
       }
       if (lane == 0) { s_base[i] = base; s_lim[i] = (uint32_t)lim; }
     }
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(GF_THREADS) void gf_filter(const uint8_t *__restric
 #pragma unroll
       for (int x = 0; x < 8; x++) acc[x] = 0;
 #pragma unroll
-      for (int b = 0; b < 16; b += 4) {
+      for (int b = 0; b < 16; b += GF_NADD) {
         uint32_t xs[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int a = 0; a < 4; a++) {          // bytes cannot carry: 4 x 63 <= 255
+        for (int a = 0; a < GF_NADD; a++) {    // bytes cannot carry: GF_NADD x GF_SAT <= 255
           const uint4 y = tabs[(b + a) * 256 + code_byte<16>(w, b + a)];
           xs[0] += y.x; xs[1] += y.y; xs[2] += y.z; xs[3] += y.w;
         }
