@@ -1359,6 +1359,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
   struct Prob {
     KmeansWorkspace ws;
     hipStream_t st = nullptr;
+    hipEvent_t assigned = nullptr;   // this problem's assignment of the iteration is final
     DevBuf<float> c_prev, c_next;
     DevBuf<int> a_prev, a_next, d_rows;
     DevBuf<unsigned> mism;
@@ -1378,7 +1379,10 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     bool done = false;
     bool shared_stream = false;
     int nrep = 0;
-    ~Prob() { if (st && !shared_stream) (void)hipStreamDestroy(st); }
+    ~Prob() {
+      if (assigned) (void)hipEventDestroy(assigned);
+      if (st && !shared_stream) (void)hipStreamDestroy(st);
+    }
   };
   std::vector<Prob> P(np);
   // ONE pinned allocation for all problems' host copies (a hipHostMalloc costs milliseconds: three per problem were
@@ -1423,7 +1427,8 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
   };
 
   DevBuf<UpdDesc> d_descs(np);
-  DevBuf<StreamDesc> d_sdescs(np);
+  DevBuf<StreamDesc> d_sdescs(np), d_odescs(np);
+  bool order_ready = false;           // stream_order has already run on the current a_prev of every active problem
   bool stream_update = true;     // every problem through kmeans_stream.hip (all or none: one batched launch pair)
   for (int p = 0; p < np; p++) stream_update = stream_update && stream_update_supported(n, k, sdim[p]);
   hipStream_t bst = nullptr;
@@ -1444,6 +1449,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     static const bool serial = getenv("GULON_KMEANS_SERIAL") != nullptr;
     if (serial) { pr.st = bst; pr.shared_stream = true; }
     else HIP_CHECK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&pr.assigned, hipEventDisableTiming));
     pr.c_prev.alloc((size_t)k * s); pr.c_next.alloc((size_t)k * s);
     pr.a_prev.alloc(n); pr.a_next.alloc(n);
     pr.mism.alloc(1);
@@ -1511,7 +1517,10 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
         D.s = sdim[p]; D.ns = stream_padded_rows(n);
         sd.push_back(D);
       }
-      kmeans_update_stream(sd, d_sdescs.p, n, k, bst);   // (sd is read by hipMemcpyAsync from pageable memory: staged before the call returns)
+      // (sd is read by hipMemcpyAsync from pageable memory: staged before the calls return)
+      if (!order_ready) kmeans_stream_order(sd, d_odescs.p, n, k, bst);
+      kmeans_stream_chains(sd, d_sdescs.p, n, k, bst);
+      order_ready = false;
     } else {
       std::vector<UpdDesc> descs;
       for (int p : act)
@@ -1545,6 +1554,23 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
         tt.iterations++; tt.rows_rechecked += fl; tt.rows_total += (unsigned long long)n * act.size();
         tt.mfma_flops += fm; tt.update_bytes += ub;
       }
+    }
+    if (stream_update && i < max_iterations) {
+      // The next update's chunk order depends on nothing but this assignment: it runs now, on the batch stream, under
+      // the convergence test's downloads and host round trip (~1 ms in which the GPU was idle).  Wasted only in the
+      // iteration that finds every problem converged.
+      std::vector<StreamDesc> sd;
+      for (int p : act) {
+        Prob &pr = P[p];
+        HIP_CHECK(hipEventRecord(pr.assigned, pr.st));
+        HIP_CHECK(hipStreamWaitEvent(bst, pr.assigned, 0));
+        StreamDesc D{};
+        D.assign = pr.a_next.p; D.xp = pr.xp.p; D.ord = pr.s_ord.p; D.coff = pr.s_coff.p; D.cout = pr.c_next.p; D.wild = pr.s_wild.p;
+        D.s = sdim[p]; D.ns = stream_padded_rows(n);
+        sd.push_back(D);
+      }
+      kmeans_stream_order(sd, d_odescs.p, n, k, bst);
+      order_ready = true;
     }
     for (int p : act) {
       Prob &pr = P[p];

@@ -132,7 +132,8 @@ size_t stream_order_words(int n, int k, size_t *coff_words);
 long long stream_padded_rows(int n);   // rows per pair of the pair-major copy (whole chunks, zero padded)
 void stream_pack_pairs(const float *xs, int n, int s, float *xp /* [pairs][ns] float2 */, int *wild /* zeroed; set if any |x| >= 2^99, infinite or NaN */,
                        hipStream_t st);
-void kmeans_update_stream(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st);
+void kmeans_stream_order(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st);
+void kmeans_stream_chains(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st);
 
 // kmeans_fused.hip: KMeans.fromAssignment without the regrouped copy (false: the shape keeps the bucketed path)
 bool kmeans_update_fused(const std::vector<UpdDesc> &descs, UpdDesc *d_descs, int n, int k, hipStream_t st);

@@ -379,7 +379,8 @@ void stream_pack_pairs(const float *xs, int n, int s, float *xp, int *wild, hipS
   HIP_CHECK(hipGetLastError());
 }
 
-void kmeans_update_stream(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st) {
+// the chunks' stable order of every problem's current assignment (descs[..].assign -> ord, coff)
+void kmeans_stream_order(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st) {
   const int np = (int)descs.size();
   if (np == 0) return;
   HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(StreamDesc) * np, hipMemcpyHostToDevice, st));
@@ -389,6 +390,14 @@ void kmeans_update_stream(const std::vector<StreamDesc> &descs, StreamDesc *d_de
   const size_t lds = sizeof(unsigned) * 5 * (size_t)k;
   hipLaunchKernelGGL(stream_order, dim3(nchunks, np), dim3(256), lds, st, d_descs, n, k, key_bits);
   HIP_CHECK(hipGetLastError());
+}
+
+// the running means along that order (xp, ord, coff -> cout)
+void kmeans_stream_chains(const std::vector<StreamDesc> &descs, StreamDesc *d_descs, int n, int k, hipStream_t st) {
+  const int np = (int)descs.size();
+  if (np == 0) return;
+  HIP_CHECK(hipMemcpyAsync(d_descs, descs.data(), sizeof(StreamDesc) * np, hipMemcpyHostToDevice, st));
+  const int nchunks = ceil_div(n, STREAM_CH);
   int pairs_max = 1;
   for (const StreamDesc &D : descs) pairs_max = std::max(pairs_max, (D.s + 1) / 2);
   const size_t chain_lds = sizeof(float) * 2 * 2 * (STREAM_CH + 8);
@@ -434,7 +443,8 @@ GULON_API int32_t gulon_selftest_stream_update(const float *x, int32_t n, int32_
     StreamDesc D;
     D.assign = a.p; D.xp = xp.p; D.ord = ord.p; D.coff = coff.p; D.cout = cout.p; D.wild = wild.p;
     D.s = s; D.pad = 0; D.ns = (long long)ns;
-    kmeans_update_stream({D}, d_desc.p, n, k, 0);
+    kmeans_stream_order({D}, d_desc.p, n, k, 0);
+    kmeans_stream_chains({D}, d_desc.p, n, k, 0);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(centroids_out, cout.p, sizeof(float) * (size_t)k * s, hipMemcpyDeviceToHost));
   });
