@@ -1555,7 +1555,8 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
         tt.mfma_flops += fm; tt.update_bytes += ub;
       }
     }
-    if (stream_update && i < max_iterations) {
+    static const bool speculate = [] { const char *e = getenv("GULON_UPDATE_SPECULATE"); return !(e && atoi(e) == 0); }();
+    if (stream_update && speculate && i < max_iterations) {
       // The next update's chunk order depends on nothing but this assignment: it runs now, on the batch stream, under
       // the convergence test's downloads and host round trip (~1 ms in which the GPU was idle).  Wasted only in the
       // iteration that finds every problem converged.
