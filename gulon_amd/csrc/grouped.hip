@@ -1353,26 +1353,18 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       auto kern = ix->vec == 16 ? gq_approx_scan<16> : gq_approx_scan<4>;
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_ga));
-      // by group with 8-bit bound tables (grouped_filter.hip): the threshold of every query from the rows of its nearest
-      // groups, then the filter; else every searched row through this kernel
-      // the nearest groups whose rows give a query its threshold: the fewest (a power of two up to 16) that hold ~1000 rows
-      static const int sample_env = [] { const char *e = getenv("GULON_GROUPED_SAMPLE"); return e ? atoi(e) : 0; }();
-      int sample_groups = 1;
-      while (sample_groups < GF_SAMPLE_GROUPS && (long long)sample_groups * gx->n < 1024ll * g) sample_groups <<= 1;
-      if (sample_env == 1 || sample_env == 2 || sample_env == 4 || sample_env == 8 || sample_env == 16) sample_groups = sample_env;
+      // by group with 8-bit bound tables (grouped_filter.hip) where a query searches more than a handful of groups; else
+      // every searched row through this kernel
       const bool by_group = gx->gfilter.built && group_filter_applies(ix->m, ix->m_pad, ix->ng, ix->vec, ix->k, ix->d) &&
                             nn_stride > GF_SAMPLE_GROUPS;
-      hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GA_WAVES), lds_ga, st, ix->codes.p, ix->ng, ix->m_pad, ix->d, gx->ptab.p,
-                         gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p,
-                         by_group ? sample_groups : INT_MAX, by_group ? GA_WAVES / sample_groups : 1, gx->apv.p, gx->api.p,
-                         gx->anan.p);
-      if (by_group) {
-        launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
-                     nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
+      if (by_group)
         group_filter_run(gx->gfilter, ix->codes.p, ix->ng, ix->vec, ix->m, ix->m_pad, ix->k, ix->d, gx->ptab.p, gx->xnorm.p, gx->xnmax,
-                         gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->amv.p, gx->apv.p, gx->api.p,
+                         gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->apv.p, gx->api.p,
                          gx->anan.p, st);
-      }
+      else
+        hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GA_WAVES), lds_ga, st, ix->codes.p, ix->ng, ix->m_pad, ix->d, gx->ptab.p,
+                           gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p, INT_MAX, 1, gx->apv.p,
+                           gx->api.p, gx->anan.p);
     }
     launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
                  nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);

@@ -12,8 +12,8 @@
 // LDS gather returns the table bytes of all sixteen queries (filter.hip's layout).  The tables are 8-bit LOWER-BOUND
 // levels of P_q (gf_quant; one set per query, shared by all its groups) plus a seventeenth table for an 8-bit level of
 // the row's |x^|^2; a row survives for a query when the summed levels fit the budget the query's threshold leaves in
-// that group.  The threshold is the 64th smallest D~ over the rows of the query's nearest groups (gq_approx_scan
-// restricted to GF_SAMPLE_GROUPS groups): real rows, so the 64 smallest of everything lie at or below it.  Survivors
+// that group.  The threshold is the 64th smallest D~ over the rows of the query's nearest groups (gf_quant scores a
+// few hundred of them itself): real rows, so the 64 smallest of everything lie at or below it.  Survivors
 // (a few hundred per query) are scored with gq_approx_scan's exact D~ arithmetic (gf_survivors), and from there the
 // pipeline is unchanged: merge to the 64 smallest, gq_rerank, certificate, literal kernels for what it rejects.
 //
@@ -170,29 +170,50 @@ __global__ void gf_tiles(const int *__restrict__ goff, const int *__restrict__ t
 // ---- per query: threshold -> step, 8-bit levels of its tables ----------------------------------------
 // qs[q] = {budget at base 0 (threshold + margin - sum of the tables' minima), 1 / step (0: keep
 // every row), -, -}.  One step = (the largest budget any of the query's groups leaves) / GF_LEVELS.
+template <int VEC>
 __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int m, int m_pad, int k, int d,
                                                 const float *__restrict__ Q, const float *__restrict__ cdist, int g,
                                                 const float *__restrict__ gnorm, float gnmax, const float *__restrict__ xnlo,
                                                 const int *__restrict__ nn, int stride, const int *__restrict__ nn_cnt,
-                                                const float *__restrict__ tau, float xnmax, float xn_step,
+                                                const uint8_t *__restrict__ codes, int ng, const float *__restrict__ xnorm,
+                                                const float *__restrict__ gcent, const int *__restrict__ bounds,
+                                                float xnmax, float xn_step,
                                                 uint8_t *__restrict__ qb, float *__restrict__ qs) {
-  extern __shared__ float qv[];                // d query coordinates
-  __shared__ float s_lo[16], s_mb[4];
-  __shared__ int s_bad;
+  extern __shared__ float gq_sm[];             // d query coordinates, the query's P table (m_pad x 256), GF_SAMPLE_ROWS values
+  float *qv = gq_sm, *tab = gq_sm + d, *vals = tab + m_pad * 256;
+  __shared__ float s_lo[16], s_mb[4], s_sbase[GF_SAMPLE_GROUPS];
+  __shared__ int s_bad, s_sc[GF_SAMPLE_GROUPS], s_sr0[GF_SAMPLE_GROUPS], s_soff[GF_SAMPLE_GROUPS + 1], s_ns;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *Pq = P + (size_t)q * m_pad * 256;
   for (int e = tid; e < d; e += 256) qv[e] = Q[(size_t)q * d + e];
+  for (int e = tid; e < m_pad * 256; e += 256) tab[e] = Pq[e];
   if (tid == 0) s_bad = 0;
+  const int ngroups = nn_cnt[q];
+  if (tid == 0) {
+    // the threshold's sample: the rows of the query's nearest groups, as many groups as it takes to reach 256 rows (at
+    // most GF_SAMPLE_GROUPS groups, at most GF_SAMPLE_ROWS rows: any rows do, they only have to be real ones)
+    int ns = 0, total = 0;
+    for (int t = 0; t < min(ngroups, GF_SAMPLE_GROUPS) && total < 256; t++) {
+      const int c = nn[(size_t)q * stride + t];
+      const int cnt = min(bounds[c + 1] - bounds[c], GF_SAMPLE_ROWS - total);
+      if (cnt <= 0) continue;
+      s_sc[ns] = c; s_sr0[ns] = bounds[c]; s_soff[ns] = total;
+      total += cnt;
+      ns++;
+    }
+    s_soff[ns] = total;
+    s_ns = ns;
+  }
   __syncthreads();
   float qq = 0.f;
   for (int e = lane; e < d; e += 64) qq += qv[e] * qv[e];
   qq = gf_wave_sum(qq);
-  const float *Pq = P + (size_t)q * m_pad * 256;
   bool bad = false;
   for (int j = wave; j < 16; j += 4) {         // the smallest entry of every table (entries from k on are never looked up)
     float lo = INFINITY;
     if (j < m)
       for (int c = lane; c < k; c += 64) {
-        const float v = Pq[j * 256 + c];
+        const float v = tab[j * 256 + c];
         bad = bad || !(fabsf(v) < INFINITY);
         lo = fminf(lo, v);
       }
@@ -200,11 +221,50 @@ __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int
     for (int o = 32; o >= 1; o >>= 1) lo = fminf(lo, __shfl_xor(lo, o));
     if (lane == 0) s_lo[j] = j < m ? lo : 0.f;
   }
+  const int ns = s_ns, total = s_soff[ns];
+  for (int t = wave; t < ns; t += 4) {         // the sampled groups' bases, gq_approx_scan's arithmetic
+    float qg = 0.f;
+    for (int e = lane; e < d; e += 64) qg += qv[e] * gcent[(size_t)s_sc[t] * d + e];
+    qg = gf_wave_sum(qg);
+    if (lane == 0) s_sbase[t] = qq - 2.0f * qg;
+  }
+  __syncthreads();
+  int n2 = 64;
+  while (n2 < total) n2 <<= 1;
+  for (int i = tid; i < n2; i += 256) {        // D~ of the sampled rows (gq_approx_scan's sum, term by term)
+    float acc = INFINITY;
+    if (i < total) {
+      int t = 0;
+      while (t + 1 < ns && i >= s_soff[t + 1]) t++;
+      const int row = s_sr0[t] + (i - s_soff[t]);
+      const uint4 w = gf_row_words<VEC>(codes, ng, row);
+      acc = s_sbase[t] + xnorm[row];
+      for (int j = 0; j < m_pad; j++) {
+        const uint32_t x = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
+        acc += tab[j * 256 + ((x >> (8 * (j & 3))) & 0xFFu)];
+      }
+      bad = bad || acc != acc;
+      if (acc != acc) acc = INFINITY;
+    }
+    vals[i] = acc;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= n2; kk <<= 1)         // ascending bitonic sort
+    for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
+      for (int i = tid; i < n2; i += 256) {
+        const int l = i ^ jj;
+        if (l > i) {
+          const float a = vals[i], b = vals[l];
+          if ((a > b) == ((i & kk) == 0)) { vals[i] = b; vals[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const float tq = total >= GF_LIST ? vals[GF_LIST - 1] : INFINITY;   // the 64th smallest D~ of real rows (+inf: keep every row)
   // a lower bound of |q|^2 - 2 q.g over the searched groups, from the centroid distances the group selection already
   // has: |q - g|^2 - |g|^2, less what the two roundings can differ by (it only sizes the step; the budgets themselves
   // use gq_approx_scan's own base)
   float mb = INFINITY;
-  const int ngroups = nn_cnt[q];
   for (int t = tid; t < ngroups; t += 256) {
     const int c = nn[(size_t)q * stride + t];
     const float base = (cdist[(size_t)q * g + c] - gnorm[c]) + xnlo[c];   // + the group's smallest row norm
@@ -222,7 +282,6 @@ __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int
   const float minbase = fminf(fminf(s_mb[0], s_mb[1]), fminf(s_mb[2], s_mb[3]));
   float sumlo = 0.f;
   for (int j = 0; j < m; j++) sumlo += s_lo[j];
-  const float tq = tau[(size_t)q * GF_LIST + GF_LIST - 1];
   const float xm = __fsqrt_rn(qq) + __fsqrt_rn(xnmax);
   const float margin = 4.0f * (float)(d + 2 * m + 16) * 5.9604645e-8f * xm * xm;     // gq_rerank's |D~ - real| bound
   const float budget0 = (tq + margin) - sumlo;
@@ -239,7 +298,7 @@ __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int
   for (int e = tid; e < GF_NT * 256; e += 256) {
     const int j = e >> 8, c = e & 255;
     int lv = 0;
-    if (j < m && c < k) lv = min(GF_SAT, max(0, (int)((Pq[j * 256 + c] - s_lo[j]) * invs)));
+    if (j < m && c < k) lv = min(GF_SAT, max(0, (int)((tab[j * 256 + c] - s_lo[j]) * invs)));
     else if (j == 16) lv = min(GF_SAT, max(0, (int)(((float)c * xn_step) * invs)));
     else if (j < m) lv = GF_SAT;
     out[e] = (uint8_t)lv;
@@ -544,7 +603,7 @@ void group_filter_build(GroupFilter &gf, const float *xnorm, int n, const float 
 
 void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d, const float *P,
                       const float *xnorm, float xnmax, const float *gcent, const int *bounds, int g, const float *Q,
-                      const float *cdist, const int *nn, int nn_stride, const int *nn_cnt, int B, const float *tau, float *apv,
+                      const float *cdist, const int *nn, int nn_stride, const int *nn_cnt, int B, float *apv,
                       int *api, int *anan, hipStream_t st) {
   const size_t pairs_max = (size_t)B * nn_stride;
   const size_t tiles_max = pairs_max / GF_QT + (size_t)g + 1;
@@ -554,8 +613,13 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
   gf.qb.ensure((size_t)B * GF_NT * 256); gf.qs.ensure((size_t)B * 4); gf.queue.ensure((size_t)B * GF_CAP);
   HIP_CHECK(hipMemsetAsync(gf.gcnt.p, 0, sizeof(int) * ((size_t)g + 1), st));
   HIP_CHECK(hipMemsetAsync(gf.qcnt.p, 0, sizeof(int) * (size_t)B, st));
-  hipLaunchKernelGGL(gf_quant, dim3(B), dim3(256), sizeof(float) * (size_t)d, st, P, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p,
-                     gf.gnmax, gf.xnlo.p, nn, nn_stride, nn_cnt, tau, xnmax, gf.xn_step, gf.qb.p, gf.qs.p);
+  {
+    const size_t lds_q = sizeof(float) * ((size_t)d + (size_t)m_pad * 256 + GF_SAMPLE_ROWS);
+    auto kern = vec == 16 ? gf_quant<16> : gf_quant<4>;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
+                       nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.qb.p, gf.qs.p);
+  }
   const dim3 pg(ceil_div(nn_stride, 256), B);
   hipLaunchKernelGGL(gf_count, pg, dim3(256), 0, st, nn, nn_stride, nn_cnt, bounds, gf.gcnt.p);
   hipLaunchKernelGGL(gf_scan, dim3(1), dim3(1024), 0, st, gf.gcnt.p, g, gf.goff.p, gf.toff.p, gf.cursor.p, gf.meta.p);

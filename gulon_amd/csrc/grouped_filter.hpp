@@ -9,7 +9,8 @@ constexpr int GF_QT = 16;       // queries per tile: one 16-byte table entry hol
 constexpr int GF_CAP = 16384;   // survivors kept per query (more: the query goes to the literal kernels)
 constexpr int GF_WAVES = 16;    // per-query lists written by gf_survivors (= gq_approx_scan's)
 constexpr int GF_LIST = 64;     // entries per list (= gq_approx_scan's)
-constexpr int GF_SAMPLE_GROUPS = 16;   // nearest groups whose rows give a query its threshold
+constexpr int GF_SAMPLE_GROUPS = 16;   // nearest groups whose rows give a query its threshold, at most
+constexpr int GF_SAMPLE_ROWS = 2048;   // ... and rows of them, at most
 
 struct GfTile {                 // one group x up to GF_QT of the queries that search it
   int c, nq, r0, r1;            // group, queries in the tile, the group's rows [r0, r1)
@@ -43,11 +44,10 @@ bool group_filter_applies(int m, int m_pad, int ng, int vec, int k, int d);
 
 // Writes, for every query, GF_WAVES lists of the GF_LIST smallest (D~, row) of its searched rows the way
 // gq_approx_scan does (apv / api: [B][GF_WAVES][GF_LIST] ascending, padded with (+inf, INT_MAX); anan: [B][GF_WAVES]
-// flags of queries that must be redone literally).  tau: [B][GF_LIST] ascending D~ of GF_LIST actual rows per query
-// (+inf padding where a query has fewer): nothing above its last entry can be among the GF_LIST smallest.
+// flags of queries that must be redone literally).
 void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d, const float *P,
                       const float *xnorm, float xnmax, const float *gcent, const int *bounds, int g, const float *Q,
                       const float *cdist /* [B][g] squared query-centroid distances */, const int *nn, int nn_stride,
-                      const int *nn_cnt, int B, const float *tau, float *apv, int *api, int *anan, hipStream_t st);
+                      const int *nn_cnt, int B, float *apv, int *api, int *anan, hipStream_t st);
 
 }  // namespace gulon
