@@ -1435,6 +1435,15 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
   bool order_ready = false;           // stream_order has already run on the current a_prev of every active problem
   bool stream_update = true;     // every problem through kmeans_stream.hip (all or none: one batched launch pair)
   for (int p = 0; p < np; p++) stream_update = stream_update && stream_update_supported(n, k, sdim[p]);
+  if (stream_update) {
+    // the streamed update keeps a second, pair-major copy of every slice (+ 4 bytes of order per row): it is taken only
+    // where that fits beside the slices and the assign's packed operands with a quarter of the device's memory to spare
+    size_t need = 0, free_b = 0, total_b = 0;
+    for (int p = 0; p < np; p++) need += (size_t)stream_padded_rows(n) * (8 * (size_t)((sdim[p] + 1) / 2) + 4);
+    for (int p = 0; p < np; p++) need += (size_t)n * (4 * (size_t)sdim[p] + 96 + 16);   // (the buffers allocated below either way)
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if (need + total_b / 4 > free_b) stream_update = false;
+  }
   hipStream_t bst = nullptr;
   hipEvent_t upd_done = nullptr;
   HIP_CHECK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
