@@ -307,6 +307,40 @@ __global__ __launch_bounds__(64) void rp_merge(const float *__restrict__ start_v
   }
 }
 
+// The K smallest distances among a flagged query's candidates so far (the bound of the long level) when level 1 went
+// through the quantized filter: every row of the earlier levels that can be among them is in the pool -- level 0's scan
+// pushes every row that entered its running list, the filter emits every level-1 row below level 0's K-th distance.
+// One wave per query.  A pool that overflowed gives no bound (the query's replay is abandoned anyway).
+__global__ __launch_bounds__(64) void rp_prefix_pool(const float *__restrict__ evv, const int *__restrict__ evcnt, int pool,
+                                                     const int *__restrict__ count, int maxf, int K,
+                                                     float *__restrict__ out_v, int *__restrict__ out_c) {
+  const int lane = threadIdx.x;
+  const int nf = min(*count, maxf);
+  for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+    const int total = evcnt[f];
+    const int n = total > pool ? 0 : total;
+    WaveList wl;
+    wl.init();
+    int cnt = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+      const bool valid = e0 + lane < n;
+      const float v = valid ? evv[(size_t)f * pool + e0 + lane] : INFINITY;
+      unsigned long long mk = __ballot(valid && (cnt < K || v < wl.tau));
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const float cv = readlane_f(v, l);
+        if (cnt < K || cv < wl.tau) {
+          wl.insert(cv, e0 + l, K, lane);
+          if (cnt < K) cnt++;
+        }
+      }
+    }
+    if (lane < K) out_v[(size_t)f * K + lane] = wl.v;
+    if (lane == 0) out_c[f] = cnt;
+  }
+}
+
 // literal TopKHeap (TopKHeap.scala) over the candidates in row order, then Result.fromHeap
 // (Index.scala:83-94).  One workgroup per flagged query:
 //   1. the candidate pool is sorted by row id (bitonic, LDS);
@@ -561,7 +595,7 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   ix->rp_l0v.ensure((size_t)F * K); ix->rp_l0i.ensure((size_t)F * K); ix->rp_l0c.ensure(F);
   ix->rp_prefix.ensure((size_t)F * K); ix->rp_precnt.ensure(F);
   ix->rp_mins.ensure((size_t)(F + 16) * std::max(ix->m_pad, ix->m));
-  ix->rp_done.ensure((size_t)3 * F);
+  ix->rp_done.ensure((size_t)4 * F);
   int *rlast_all = fin_i && !ix->wide ? ix->rp_done.p + 2 * F : nullptr;   // (rp_shortcut writes the same values again)
   hipLaunchKernelGGL(rp_gather_queries, dim3(ceil_div((long long)F * ix->d, 256)), dim3(256), 0, st, dQ, ix->d, F,
                      pk.list(), pk.count(), ix->rp_q.p, K, fin_i, fin_c, rlast_all);
@@ -591,11 +625,31 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   // level 0: cold start over the first rows -> their K smallest distances
   scan(rb_begin, rb_begin + l0, l0, 1, nullptr, nullptr, ix->rp_l0v.p, ix->rp_l0i.p, ix->rp_l0c.p, gy_short, nullptr);
   if (segs1 > 0) {
-    scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
-         ix->rp_segi.p, ix->rp_segcnt.p, gy_short, nullptr);
+    // Level 1 (the next 131 K rows) tightens the bound for the long level.  As an exact fp32 scan it was the replay's
+    // largest kernel when every query of a batch ties (0.6 ms of LDS gathers); with level 0's K-th distance as a fixed
+    // bound it is a threshold query over 2048 row blocks -- 1 % of a main stage for the quantized filter -- and the long
+    // level's bound is then read off the candidate pool.  Batches with few flagged queries keep the segment scan.
+    int *only1 = nullptr;
+    bool l1_filtered = false;
+    static const bool l1_off = [] { const char *e = getenv("GULON_REPLAY_L1_FILTER"); return e && atoi(e) == 0; }();
+    if (!l1_off && recently_flagged >= 32 && segs2 > 0 && !ix->wide)
+      l1_filtered = replay_level2_filtered(ix, F, K, rb_begin + l0, rb_begin + l0 + l1, from,
+                                           std::min(until, (rb_begin + l0 + l1) * 64), ix->rp_tables.p, ix->rp_mins.p,
+                                           ix->rp_l0v.p, ix->rp_l0c.p, pk.count(), pk.evv(), pk.evi(), pk.evcnt(), C, &only1, st,
+                                           nullptr, rlast_all, ix->rp_done.p + 3 * F);
+    if (l1_filtered)   // (the queries the filter left over: overflowing queues, no bound yet)
+      scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, ix->rp_l0v.p, ix->rp_l0c.p, nullptr, nullptr, nullptr, gy_short,
+           only1);
+    else
+      scan(rb_begin + l0, rb_begin + l0 + l1, RP_L1_SEG, segs1, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
+           ix->rp_segi.p, ix->rp_segcnt.p, gy_short, nullptr);
     if (segs2 > 0) {
-      hipLaunchKernelGGL(rp_merge, dim3(std::min(F, 1024)), dim3(64), 0, st, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
-                         ix->rp_segi.p, pk.count(), F, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
+      if (l1_filtered)
+        hipLaunchKernelGGL(rp_prefix_pool, dim3(std::min(F, 1024)), dim3(64), 0, st, pk.evv(), pk.evcnt(), C, pk.count(), F, K,
+                           ix->rp_prefix.p, ix->rp_precnt.p);
+      else
+        hipLaunchKernelGGL(rp_merge, dim3(std::min(F, 1024)), dim3(64), 0, st, ix->rp_l0v.p, ix->rp_l0c.p, ix->rp_segtop.p,
+                           ix->rp_segi.p, pk.count(), F, segs1, K, ix->rp_prefix.p, ix->rp_precnt.p);
       HIP_CHECK(hipGetLastError());
       // The long level.  Its segment scans are an exact fp32 scan of (nearly) all rows per flagged query, one query's
       // table per workgroup: 27 us per query, 28 ms when all 1024 queries of a batch tie (the reference-shaped data).
@@ -605,7 +659,6 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
       // road, and the segment scan below only walks the queries left to it (`only`).
       int *only = nullptr;
       const int *done = nullptr, *rlast = nullptr;
-      ix->rp_done.ensure((size_t)3 * F);
       if (fin_d && !ix->wide) {
         hipLaunchKernelGGL(rp_shortcut, dim3(ceil_div(F, 256)), dim3(256), 0, st, pk.count(), pk.list(), F, K, ix->rp_prefix.p,
                            ix->rp_precnt.p, fin_d, fin_i, fin_c, (rb_begin + l0 + l1) * 64 + ix->row_base, C, pk.evv(), pk.evi(),
