@@ -36,7 +36,10 @@ constexpr int RP_LDS_POOL = 16384;   // candidates rp_heap can sort in LDS (all 
 #ifndef GULON_RP_L1_SEG
 #define GULON_RP_L1_SEG 64
 #endif
-constexpr int RP_L0_BLOCKS = 64, RP_L1_BLOCKS = GULON_RP_L1_BLOCKS, RP_L1_SEG = GULON_RP_L1_SEG, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
+#ifndef GULON_RP_L0_BLOCKS
+#define GULON_RP_L0_BLOCKS 64
+#endif
+constexpr int RP_L0_BLOCKS = GULON_RP_L0_BLOCKS, RP_L1_BLOCKS = GULON_RP_L1_BLOCKS, RP_L1_SEG = GULON_RP_L1_SEG, RP_L2_SEGS = 2048, RP_L2_MIN = 16;
 
 // Candidate buffer ("pack", int32 words) for F flagged queries with C candidates each:
 //   [0] flagged queries in this pack (<= F)   [1] F   [2] C   [3] flagged queries of the whole batch
@@ -582,7 +585,10 @@ void replay_collect(gulon_index *ix, const float *dQ, int B, int K, int from, in
   const int gy = std::min(F, 16);
   const int gy_short = recently_flagged >= 32 ? std::min(F, 256) : gy;
   // level geometry (in 64-row blocks)
-  const int l0 = std::min(rb_total, RP_L0_BLOCKS);
+  // (level 0 is one wave per query walking its blocks one after the other: short where a batch has a flagged query or
+  // two -- its latency is the replay's -- and four times as long where most of the batch ties: level 1's bound, the K-th
+  // distance of level 0's rows, then lets a quarter as many rows through the filter)
+  const int l0 = std::min(rb_total, recently_flagged >= 32 ? 4 * RP_L0_BLOCKS : RP_L0_BLOCKS);
   const int l1 = std::min(rb_total - l0, RP_L1_BLOCKS);
   const int l2 = rb_total - l0 - l1;
   const int segs1 = ceil_div(l1, RP_L1_SEG);
