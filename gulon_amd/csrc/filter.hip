@@ -678,7 +678,49 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
       }
       return wn;
     };
+    // the same with the word's number a compile-time constant: table addresses are  (code byte << log2 entry size) +
+    // literal, as in the one-word form (the tables sit at LDS address 0); taken where the index has exactly NGC words
+    auto word_c = [&](auto gc, const Word w) __attribute__((always_inline)) -> Word {
+      constexpr int g = decltype(gc)::value;
+      Word wn = w;
+      if (g + 1 < ng) wn = p[(size_t)(g + 1) * 64];
+      typedef unsigned lvec __attribute__((ext_vector_type(DW)));
+#pragma unroll
+      for (int b = 0; b < VEC; b += NADD) {
+        uint32_t c[NADD];
+#pragma unroll
+        for (int a = 0; a < NADD; a++) c[a] = code_byte<VEC>(w, b + a);
+#pragma unroll
+        for (int s = 0; s < NQG; s++) {
+          uint32_t xs[DW];
+#pragma unroll
+          for (int dd = 0; dd < DW; dd++) xs[dd] = 0;
+#pragma unroll
+          for (int a = 0; a < NADD; a++) {   // bytes cannot carry: NADD * QMAX <= 255
+            const int e = g * VEC + b + a;
+            const lvec y = reinterpret_cast<const __attribute__((address_space(3))) lvec *>(0)[e * 256 + c[a] + s * tab];
+#pragma unroll
+            for (int dd = 0; dd < DW; dd++) xs[dd] += y[dd];
+          }
+#pragma unroll
+          for (int dd = 0; dd < DW; dd++) {
+            acc[s][2 * dd] += xs[dd] & 0x00FF00FFu;
+            acc[s][2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
+          }
+        }
+      }
+      return wn;
+    };
     if constexpr (NG1) (void)word(0, std::true_type{}, w);
+#ifndef GULON_FILTER_WORDS_LOOP
+#define WC(G) w = word_c(std::integral_constant<int, G>{}, w)
+    // (the two forms measured: BASELINE config 5's m = 64 -- 15.16 -> 14.5 ms per batch -- and the reference CLI's default
+    // m = 25 -- 0.759 -> 0.716 ms.  Unrolled for every word count the kernels grew to the 128-register limit, and the
+    // m = 32 form (two 16-byte words, 16-byte entries) aborted; the others keep the loop.)
+    else if (QW == 8 && VEC == 16 && ng == 4) { WC(0); WC(1); WC(2); WC(3); }
+    else if (QW == 16 && VEC == 4 && ng == 7) { WC(0); WC(1); WC(2); WC(3); WC(4); WC(5); WC(6); }
+#undef WC
+#endif
     else
       for (int g = 0; g < ng; g++) w = word(g, std::false_type{}, w);
 
