@@ -1356,7 +1356,7 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       // by group with 8-bit bound tables (grouped_filter.hip) where a query searches more than a handful of groups; else
       // every searched row through this kernel
       const bool by_group = gx->gfilter.built && group_filter_applies(ix->m, ix->m_pad, ix->ng, ix->vec, ix->k, ix->d) &&
-                            nn_stride > GF_SAMPLE_GROUPS;
+                            nn_stride > GF_SAMPLE_GROUPS && B <= 65535;   // (a grid's y extent carries the query)
       if (by_group)
         group_filter_run(gx->gfilter, ix->codes.p, ix->ng, ix->vec, ix->m, ix->m_pad, ix->k, ix->d, gx->ptab.p, gx->xnorm.p, gx->xnmax,
                          gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->apv.p, gx->api.p,
