@@ -1347,8 +1347,6 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
     gx->apv.ensure((size_t)B * GA_WAVES * GA_C); gx->api.ensure((size_t)B * GA_WAVES * GA_C);
     gx->amv.ensure((size_t)B * GA_C); gx->ami.ensure((size_t)B * GA_C);
     gx->anan.ensure((size_t)B * GA_WAVES);
-    hipLaunchKernelGGL(gq_ptables, dim3(ix->m_pad, B), dim3(256), 0, st, ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m,
-                       ix->m_pad, ix->k, dQ, gx->ptab.p);
     {
       auto kern = ix->vec == 16 ? gq_approx_scan<16> : gq_approx_scan<4>;
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1357,17 +1355,22 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       // every searched row through this kernel
       const bool by_group = gx->gfilter.built && group_filter_applies(ix->m, ix->m_pad, ix->ng, ix->vec, ix->k, ix->d) &&
                             nn_stride > GF_SAMPLE_GROUPS && B <= 65535;   // (a grid's y extent carries the query)
+      if (!by_group)   // (the by-group path builds the tables where it quantizes them)
+        hipLaunchKernelGGL(gq_ptables, dim3(ix->m_pad, B), dim3(256), 0, st, ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m,
+                           ix->m_pad, ix->k, dQ, gx->ptab.p);
       if (by_group)
-        group_filter_run(gx->gfilter, ix->codes.p, ix->ng, ix->vec, ix->m, ix->m_pad, ix->k, ix->d, gx->ptab.p, gx->xnorm.p, gx->xnmax,
-                         gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->apv.p, gx->api.p,
+        group_filter_run(gx->gfilter, ix->codes.p, ix->ng, ix->vec, ix->m, ix->m_pad, ix->k, ix->d, gx->ptab.p, ix->cents.p,
+                         ix->from.p, ix->sdim.p, gx->xnorm.p, gx->xnmax,
+                         gx->gcent.p, gx->bounds.p, g, dQ, gx->cdist.p, gx->nn.p, nn_stride, gx->nn_cnt.p, B, gx->amv.p, gx->ami.p,
                          gx->anan.p, st);
-      else
+      else {
         hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GA_WAVES), lds_ga, st, ix->codes.p, ix->ng, ix->m_pad, ix->d, gx->ptab.p,
                            gx->xnorm.p, gx->gcent.p, gx->bounds.p, dQ, gx->nn.p, nn_stride, gx->nn_cnt.p, INT_MAX, 1, gx->apv.p,
                            gx->api.p, gx->anan.p);
+        launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
+                     nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
+      }
     }
-    launch_merge(false, gx->apv.p, gx->api.p, GA_WAVES, (long long)GA_C, (long long)GA_WAVES * GA_C, B, GA_C - 1, nullptr,
-                 nullptr, nullptr, nullptr, gx->amv.p, gx->ami.p, st);
     hipLaunchKernelGGL(gq_rerank, dim3(B), dim3(64), 0, st, ix->codes.p, ix->ng, ix->vec, ix->m, ix->k, ix->d, ix->cents.p,
                        ix->from.p, ix->sdim.p, gx->gcent.p, gx->bounds.p, g, dQ, gx->amv.p, gx->ami.p, gx->anan.p, gx->xnmax,
                        K, d_oi, d_od, d_oc, gx->qlist.p, gx->qcount.p);

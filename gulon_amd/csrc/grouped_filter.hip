@@ -108,14 +108,6 @@ __global__ void gf_gnorm(const float *__restrict__ gcent, int g, int d, float *_
 }
 
 // ---- per batch: for every group the queries that search it -------------------------------------------
-__global__ void gf_count(const int *__restrict__ nn, int stride, const int *__restrict__ nn_cnt, const int *__restrict__ bounds,
-                         int *__restrict__ gcnt) {
-  const int q = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nn_cnt[q]) return;
-  const int c = nn[(size_t)q * stride + t];
-  if (bounds[c + 1] > bounds[c]) atomicAdd(&gcnt[c], 1);
-}
-
 // goff: first pair of every group, toff: first tile (GF_QT pairs) of every group; meta[0] = tiles
 __global__ __launch_bounds__(1024) void gf_scan(const int *__restrict__ gcnt, int g, int *__restrict__ goff, int *__restrict__ toff,
                                                 int *__restrict__ cursor, int *__restrict__ meta) {
@@ -171,23 +163,38 @@ __global__ void gf_tiles(const int *__restrict__ goff, const int *__restrict__ t
 // qs[q] = {budget at base 0 (threshold + margin - sum of the tables' minima), 1 / step (0: keep
 // every row), -, -}.  One step = (the largest budget any of the query's groups leaves) / GF_LEVELS.
 template <int VEC>
-__global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int m, int m_pad, int k, int d,
+__global__ __launch_bounds__(256) void gf_quant(float *__restrict__ P /* out: the query's table, gq_ptables' */,
+                                                const float *__restrict__ pq_cents, const int *__restrict__ from,
+                                                const int *__restrict__ sdim, int m, int m_pad, int k, int d,
                                                 const float *__restrict__ Q, const float *__restrict__ cdist, int g,
                                                 const float *__restrict__ gnorm, float gnmax, const float *__restrict__ xnlo,
                                                 const int *__restrict__ nn, int stride, const int *__restrict__ nn_cnt,
                                                 const uint8_t *__restrict__ codes, int ng, const float *__restrict__ xnorm,
                                                 const float *__restrict__ gcent, const int *__restrict__ bounds,
-                                                float xnmax, float xn_step,
+                                                float xnmax, float xn_step, int *__restrict__ gcnt,
                                                 uint8_t *__restrict__ qb, float *__restrict__ qs) {
   extern __shared__ float gq_sm[];             // d query coordinates, the query's P table (m_pad x 256), GF_SAMPLE_ROWS values
   float *qv = gq_sm, *tab = gq_sm + d, *vals = tab + m_pad * 256;
   __shared__ float s_lo[16], s_mb[4], s_sbase[GF_SAMPLE_GROUPS];
   __shared__ int s_bad, s_sc[GF_SAMPLE_GROUPS], s_sr0[GF_SAMPLE_GROUPS], s_soff[GF_SAMPLE_GROUPS + 1], s_ns;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *Pq = P + (size_t)q * m_pad * 256;
+  float *Pq = P + (size_t)q * m_pad * 256;
   for (int e = tid; e < d; e += 256) qv[e] = Q[(size_t)q * d + e];
-  for (int e = tid; e < m_pad * 256; e += 256) tab[e] = Pq[e];
   if (tid == 0) s_bad = 0;
+  __syncthreads();
+  // the query's table P[j][c] = -2 (q_j . c_j[c]) -- gq_ptables' arithmetic, term by term -- into LDS and out to memory
+  // (gf_survivors reads it there): thread = centroid
+  for (int j = 0; j < m_pad; j++) {
+    float acc = 0.f;
+    if (j < m && tid < k) {
+      const int fr = from[j], sj = sdim[j];
+      const float *cc = pq_cents + (size_t)k * fr + (size_t)tid * sj;
+      for (int t = 0; t < sj; t++) acc += qv[fr + t] * cc[t];
+      acc *= -2.0f;
+    }
+    tab[j * 256 + tid] = acc;
+    Pq[j * 256 + tid] = acc;
+  }
   const int ngroups = nn_cnt[q];
   if (tid == 0) {
     // the threshold's sample: the rows of the query's nearest groups, as many groups as it takes to reach 256 rows (at
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(256) void gf_quant(const float *__restrict__ P, int
   float mb = INFINITY;
   for (int t = tid; t < ngroups; t += 256) {
     const int c = nn[(size_t)q * stride + t];
+    if (bounds[c + 1] > bounds[c]) atomicAdd(&gcnt[c], 1);                // the group's list of queries grows by this one
     const float base = (cdist[(size_t)q * g + c] - gnorm[c]) + xnlo[c];   // + the group's smallest row norm
     bad = bad || !(fabsf(base) < INFINITY);
     mb = fminf(mb, base);
@@ -557,10 +565,30 @@ __global__ __launch_bounds__(64 * GF_WAVES) void gf_survivors(const uint8_t *__r
       }
     }
   }
-  const size_t o = ((size_t)q * GF_WAVES + wave) * GF_LIST;
-  lv[o + lane] = wl.v;
-  li[o + lane] = wl.i;
-  if (lane == 0) nanflag[q * GF_WAVES + wave] = saw_nan;
+  // the sixteen waves' lists -> the query's GF_LIST smallest, ascending by (value, row): what merge_lists makes of
+  // gq_approx_scan's lists, here by one bitonic sort of the 1024 entries in LDS (the table is no longer needed)
+  __shared__ int s_nan;
+  if (tid == 0) s_nan = 0;
+  __syncthreads();
+  float *sv = tab;
+  int *si = reinterpret_cast<int *>(tab + 64 * GF_WAVES);
+  sv[tid] = wl.v;
+  si[tid] = wl.i;
+  if (lane == 0 && saw_nan) atomicOr(&s_nan, 1);
+  __syncthreads();
+  for (int kk = 2; kk <= 64 * GF_WAVES; kk <<= 1)
+    for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
+      const int l = tid ^ jj;
+      if (l > tid) {
+        const float a = sv[tid], b = sv[l];
+        const int ai = si[tid], bi = si[l];
+        const bool gt = a > b || (a == b && ai > bi);
+        if (gt == ((tid & kk) == 0)) { sv[tid] = b; sv[l] = a; si[tid] = bi; si[l] = ai; }
+      }
+      __syncthreads();
+    }
+  if (tid < GF_LIST) { lv[(size_t)q * GF_LIST + tid] = sv[tid]; li[(size_t)q * GF_LIST + tid] = si[tid]; }
+  if (tid < GF_WAVES) nanflag[q * GF_WAVES + tid] = tid == 0 ? s_nan : 0;
 }
 
 }  // namespace
@@ -601,10 +629,11 @@ void group_filter_build(GroupFilter &gf, const float *xnorm, int n, const float 
   gf.built = true;
 }
 
-void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d, const float *P,
+void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d, float *P,
+                      const float *pq_cents, const int *from, const int *sdim,
                       const float *xnorm, float xnmax, const float *gcent, const int *bounds, int g, const float *Q,
-                      const float *cdist, const int *nn, int nn_stride, const int *nn_cnt, int B, float *apv,
-                      int *api, int *anan, hipStream_t st) {
+                      const float *cdist, const int *nn, int nn_stride, const int *nn_cnt, int B, float *amv,
+                      int *ami, int *anan, hipStream_t st) {
   const size_t pairs_max = (size_t)B * nn_stride;
   const size_t tiles_max = pairs_max / GF_QT + (size_t)g + 1;
   GULON_UNSUPPORTED(tiles_max >= (1ull << 31), "too many (query, group) pairs");
@@ -617,11 +646,10 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
     const size_t lds_q = sizeof(float) * ((size_t)d + (size_t)m_pad * 256 + GF_SAMPLE_ROWS);
     auto kern = vec == 16 ? gf_quant<16> : gf_quant<4>;
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
-                       nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.qb.p, gf.qs.p);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, pq_cents, from, sdim, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
+                       nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.gcnt.p, gf.qb.p, gf.qs.p);
   }
   const dim3 pg(ceil_div(nn_stride, 256), B);
-  hipLaunchKernelGGL(gf_count, pg, dim3(256), 0, st, nn, nn_stride, nn_cnt, bounds, gf.gcnt.p);
   hipLaunchKernelGGL(gf_scan, dim3(1), dim3(1024), 0, st, gf.gcnt.p, g, gf.goff.p, gf.toff.p, gf.cursor.p, gf.meta.p);
   hipLaunchKernelGGL(gf_fill, pg, dim3(256), 0, st, nn, nn_stride, nn_cnt, bounds, gf.goff.p, gf.cursor.p,
                      gf.pairs.p);
@@ -655,8 +683,9 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
   }
   {
     auto kern = vec == 16 ? gf_survivors<16> : gf_survivors<4>;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GF_WAVES), sizeof(float) * (size_t)m_pad * 256, st, codes, ng, m_pad, P, xnorm,
-                       gf.qcnt.p, gf.queue.p, apv, api, anan);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GF_WAVES), sizeof(float) * std::max((size_t)m_pad * 256, (size_t)2 * 64 * GF_WAVES), st,
+                       codes, ng, m_pad, P, xnorm,
+                       gf.qcnt.p, gf.queue.p, amv, ami, anan);
   }
   HIP_CHECK(hipGetLastError());
 }

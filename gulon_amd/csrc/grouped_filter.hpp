@@ -42,12 +42,14 @@ void group_filter_build(GroupFilter &gf, const float *xnorm, int n, const float 
 // row), at most 256 centroids per quantizer.
 bool group_filter_applies(int m, int m_pad, int ng, int vec, int k, int d);
 
-// Writes, for every query, GF_WAVES lists of the GF_LIST smallest (D~, row) of its searched rows the way
-// gq_approx_scan does (apv / api: [B][GF_WAVES][GF_LIST] ascending, padded with (+inf, INT_MAX); anan: [B][GF_WAVES]
-// flags of queries that must be redone literally).
-void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d, const float *P,
+// Writes, for every query, the GF_LIST smallest (D~, row) of its searched rows, ascending by (D~, row) and padded with
+// (+inf, INT_MAX) -- what gq_approx_scan + merge_lists produce (amv / ami: [B][GF_LIST]) -- and anan ([B][GF_WAVES]: a
+// non-zero entry sends the query to the literal kernels).
+void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, int m, int m_pad, int k, int d,
+                      float *P /* out: [B][m_pad][256], the queries' -2 q.c tables (gq_ptables') */, const float *pq_cents,
+                      const int *from, const int *sdim,
                       const float *xnorm, float xnmax, const float *gcent, const int *bounds, int g, const float *Q,
                       const float *cdist /* [B][g] squared query-centroid distances */, const int *nn, int nn_stride,
-                      const int *nn_cnt, int B, float *apv, int *api, int *anan, hipStream_t st);
+                      const int *nn_cnt, int B, float *amv, int *ami, int *anan, hipStream_t st);
 
 }  // namespace gulon
