@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   extern __shared__ float sel_lds[];
   float *sv = sel_lds;                                     // [cap]
   int *si = reinterpret_cast<int *>(sel_lds + cap);        // [cap]
-  __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_remaining;
+  __shared__ unsigned hist[256], hsub[256 * 8];   // (eight sub-counters per bin: centroid distances share their high bytes,
+  __shared__ unsigned s_prefix, s_remaining;      //  and 10 000 atomics on one or two LDS words serialise)
   __shared__ int s_count, s_lit;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float *dq = cdist + (size_t)q * g;
@@ -290,12 +290,19 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   __syncthreads();
   unsigned mask = 0u;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    hist[tid] = 0u;
+    for (int e = tid; e < 256 * 8; e += 256) hsub[e] = 0u;
     __syncthreads();
     const unsigned prefix = s_prefix;
     for (int c = tid; c < g; c += 256) {
       const unsigned key = keyof(c);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      if ((key & mask) == prefix) atomicAdd(&hsub[((key >> shift) & 255u) * 8 + (tid & 7)], 1u);
+    }
+    __syncthreads();
+    {
+      unsigned h = 0;
+#pragma unroll
+      for (int x = 0; x < 8; x++) h += hsub[tid * 8 + x];
+      hist[tid] = h;
     }
     __syncthreads();
     if (tid == 0) {
