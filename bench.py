@@ -77,11 +77,12 @@ def extras(args, g, N, L, torch, dev, HipEngine, ShardedIndex, local_shard, reca
 
     # 1. the exact scan (every look-up in fp32, no 8-bit filter): the path small ranges, wide indexes and the
     #    safety net take
-    N.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 0))
+    g.tune_live(GULON_SCAN_FILTER=0)     # every open handle and context (and the environment, for new ones)
     try:
         ms, _ = run_steps(torch, shardeds, streams, Q, B, K, min(steps, 3))
     finally:
-        N.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 1))
+        g.tune_live(GULON_SCAN_FILTER=1)
+        os.environ.pop("GULON_SCAN_FILTER", None)
     ex["exact_scan"] = {"ms_per_step": ms, "queries_per_s": B / ms * 1e3,
                         "what": "GULON_SCAN_FILTER=0: same index and queries, every (query,row,quantizer) look-up in fp32"}
     note("extras: exact scan")

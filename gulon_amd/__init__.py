@@ -2,7 +2,7 @@
 Index / ProductQuantizer / KMeans API (host mirror over libgulon_hip.so)."""
 from . import native
 from .coder import Coder, width_for_clusters
-from .index import Index, PQIndex, Result, SortedIndex, exact_nearest_neighbours, prepare_query
+from .index import Index, PQIndex, Result, SortedIndex, exact_nearest_neighbours, prepare_query, tune_live
 from .grouped import GroupedIndex, GroupedVectors, LimitGroups, LimitVectors, group
 from .kmeans import KMeans
 from .kmeans import Config as KMeansConfig
@@ -14,7 +14,7 @@ from .word_vectors import (GroupedWordVectors, KeyedIndex, KeyIndexGrouped, KeyI
                            read_word2vec)
 
 __all__ = ["native", "GroupedIndex", "GroupedVectors", "LimitGroups", "LimitVectors", "group", "Coder", "width_for_clusters", "Index", "PQIndex", "Result", "SortedIndex",
-           "exact_nearest_neighbours", "prepare_query", "KMeans", "KMeansConfig", "DeviceMatrix", "Matrix",
+           "exact_nearest_neighbours", "prepare_query", "tune_live", "KMeans", "KMeansConfig", "DeviceMatrix", "Matrix",
            "EncodedMatrix", "ProductQuantizer", "Quantizer", "ProductQuantizerConfig", "Vectors",
            "subvector_bounds", "subvectors", "GroupedWordVectors", "KeyedIndex", "KeyIndexGrouped", "KeyIndexSorted",
            "WordVectors", "read_word2vec"]

@@ -659,7 +659,9 @@ bool ScanTuning::set(const char *key, int v) {
   return true;
 }
 
-ScanTuning &tuning() { static ScanTuning t; return t; }
+// The knobs have no process-wide mutable state: a handle takes its settings from the ENVIRONMENT when it is created
+// (ScanTuning's constructor) and keeps them; gulon_index_tuning changes one handle.  (A null handle: the compiled-in defaults.)
+const ScanTuning &tuning_defaults() { static const ScanTuning t; return t; }
 
 bool replay_enabled() {
   static const bool on = [] { const char *e = getenv("GULON_TIE_REPLAY"); return !(e && atoi(e) == 0); }();
@@ -938,6 +940,7 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
     int width = -1;
     GULON_REQUIRE(gulon_coder_width(k, &width) == GULON_OK && width >= 0, "too many clusters: %d", k);  // PQ.scala:12-15
     std::unique_ptr<gulon_index> ix(new gulon_index());
+    ix->tune = std::make_shared<ScanTuning>();   // the environment as it is now
     ix->n = n; ix->d = d; ix->m = m; ix->k = k; ix->row_base = row_base;
     if (k > 256) {
       // Coder.BytePlus widths 10/12/16 (Coder.scala:99-127): 16-bit codes, tables in HBM (wide.hip)
@@ -1018,8 +1021,8 @@ GULON_API int32_t gulon_index_create(const uint8_t *codes, int32_t n, int32_t d,
       HIP_CHECK(hipDeviceSynchronize());
       // the filter's conflict-ordered copy (one 16-byte code word per row; ranges the filter is never used for
       // do not need one).  GULON_FILTER_ORDER = rounds of the ordering (0: no copy)
-      const int rounds = tuning().filter_order;
-      if (rounds > 0 && ix->vec == 16 && ix->ng == 1 && (long long)nblk >= tuning().filter_min_rb) {
+      const int rounds = ix->tune->filter_order;
+      if (rounds > 0 && ix->vec == 16 && ix->ng == 1 && (long long)nblk >= ix->tune->filter_min_rb) {
         ix->fcodes.alloc(nblk * 1024);
         ix->fperm.alloc(nblk * 64);
         launch_conflict_order(ix->codes.p, ix->fcodes.p, ix->fperm.p, (long long)nblk, FILTER_LDS_QUANTIZERS, rounds, 0);
@@ -1267,12 +1270,6 @@ GULON_API int32_t gulon_index_tuning(gulon_index *idx, const char *key, int32_t 
     auto t = std::make_shared<ScanTuning>(tuning_of(idx));
     GULON_REQUIRE(t->set(key, value), "unknown tuning key");
     idx->tune = t;
-  });
-}
-
-GULON_API int32_t gulon_scan_tuning(const char *key, int32_t value) {
-  return guarded([&] {
-    GULON_REQUIRE(key != nullptr && tuning().set(key, value), "unknown tuning key");
   });
 }
 

@@ -27,8 +27,8 @@ namespace gulon { struct ScanTuning; }
 // PQIndex on the device (opaque to C callers)
 using gulon::DevBuf;
 struct gulon_index {
-  // launch-shape / algorithm knobs of THIS handle (gulon_index_tuning); null: the process-wide defaults
-  // (gulon_scan_tuning).  Contexts inherit their parent's at creation.
+  // launch-shape / algorithm knobs of THIS handle: the environment at its creation, then gulon_index_tuning.  Contexts
+  // inherit their parent's at creation.
   std::shared_ptr<gulon::ScanTuning> tune;
   int32_t n = 0, d = 0, m = 0, k = 0, row_base = 0;
   int vec = 16, ng = 1, m_pad = 16, nsub = 1, w = 4;   // w: queries interleaved per table entry
@@ -149,7 +149,7 @@ inline int rbmap_count(int rb_total, RbMap mp) {
   return (rb_total / mp.period) * mp.width + extra;
 }
 
-// launch shape knobs (environment overrides / gulon_scan_tuning are for experiments and tests)
+// launch shape knobs (the environment at index creation / gulon_index_tuning: for experiments and tests)
 // filter.hip: of the 16 quantizers of a one-word code, the entries of the last GULON_FILTER_GLB are fetched through
 // the vector L1 instead of LDS; conflict_order.hip orders rows for the bank conflicts of the others
 #ifndef GULON_FILTER_GLB
@@ -173,12 +173,12 @@ struct ScanTuning {
   int filter_nadd = 0;       // table entries summed in 8 bits before widening (2: 7-bit, 4: 6-bit levels, 0: by m)
   int filter_blocks = 4096;         // workgroups aimed for by a filter launch
   int filter_shared_stage1 = -1;    // bounds shared across shards: run the short first stage? (-1: by sample size)
-  int filter_order = 1;             // conflict-ordered code copy: built at index creation (process-wide value) / used (per handle)
+  int filter_order = 1;             // conflict-ordered code copy: built at index creation (the environment's value) / used (per handle)
   ScanTuning();
   bool set(const char *key, int v);
 };
-ScanTuning &tuning();
-inline const ScanTuning &tuning_of(const gulon_index *ix) { return ix && ix->tune ? *ix->tune : tuning(); }
+const ScanTuning &tuning_defaults();
+inline const ScanTuning &tuning_of(const gulon_index *ix) { return ix && ix->tune ? *ix->tune : tuning_defaults(); }
 
 // wide.hip: indexes with more than 256 centroids per quantizer (code widths 10/12/16)
 void wide_store_codes(gulon_index *ix, const uint16_t *wide16 /* device, [m][n] */);

@@ -1,5 +1,7 @@
 """Index (Index.scala): prepareQuery, PQIndex, SortedIndex, exactNearestNeighbours."""
 import ctypes as C
+import os
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -52,6 +54,20 @@ def exact_nearest_neighbours(vectors, query, k, frm=0, until=None):
     return res[0] if single else res
 
 
+_LIVE = weakref.WeakSet()     # open PQIndex handles and contexts (tune_live)
+
+
+def tune_live(**knobs):
+    """Tuning experiments and tests: sets the launch-shape knobs (GULON_SCAN_FILTER=0, GULON_FILTER_CAP=64, ...) in the
+    environment -- where every handle created from now on takes them from -- and on every open handle and context
+    (gulon_index_tuning).  The library has no process-wide setter; results never depend on the knobs."""
+    for key, value in knobs.items():
+        os.environ[key] = str(int(value))
+        for ix in list(_LIVE):
+            if ix._h is not None and ix._h.value:
+                N.check(N.lib().gulon_index_tuning(ix._h, key.encode(), int(value)))
+
+
 class PQIndex:
     """PQIndex(productQuantizer, data) (Index.scala:385-441): owns the HBM copy of the codes."""
 
@@ -59,6 +75,7 @@ class PQIndex:
         self.product_quantizer = product_quantizer
         self.data = data
         self.row_base = row_base
+        _LIVE.add(self)
         if _handle is not None:
             self._h = _handle
             return

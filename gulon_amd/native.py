@@ -116,7 +116,6 @@ SIGNATURES = {
     "gulon_index_profile_read_ex": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "gulon_index_filter_stats": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gulon_index_tuning": (_i32, [_vp, C.c_char_p, _i32]),
-    "gulon_scan_tuning": (_i32, [C.c_char_p, _i32]),
     "gulon_nan_queries_fix_dev": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gulon_topk_merge": (_i32, [_f32p, _i32p, _i32, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),
     "gulon_exact_knn": (_i32, [_vp, _i32, _i32, _f32p, _i32, _i32, _i32p, _f32p, _i32p, _i32p]),

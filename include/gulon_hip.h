@@ -359,16 +359,15 @@ int32_t gulon_index_profile_read_ex(gulon_index *idx, double *ms_total, int32_t 
  * and how many of them the device-side safety net redid with the exact scan (unusable bound or survivor-queue
  * overflow).  query_tiles = 0: the batch took the exact scan. */
 int32_t gulon_index_filter_stats(gulon_index *idx, int32_t *query_tiles, int32_t *tiles_redone);
-/* Launch-shape / algorithm knobs of the scan, process-wide (tests and tuning experiments):
- * key = the name of the corresponding environment variable, e.g. "GULON_SCAN_FILTER" (0/1),
- * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE1", "GULON_FILTER_CAP",
- * "GULON_FILTER_NADD", "GULON_SCAN_BLOCKS", "GULON_SCAN_PRUNE".  Results never depend on them.
- * "GULON_FILTER_ORDER" (default 1): an index of one-word codes (m <= 16) created while it is non-zero keeps a second,
- * conflict-ordered copy of its codes for the filter kernel (+ 17 bytes per row; the value = rounds of the ordering);
- * per handle (gulon_index_tuning) 0 makes the filter read the plain copy again. */
-int32_t gulon_scan_tuning(const char *key, int32_t value);
-/* The same knobs for ONE handle (and the contexts created from it afterwards): two indexes of a process can be
- * tuned independently; a handle without settings of its own follows the process-wide ones. */
+/* Launch-shape / algorithm knobs of the scan, per handle (tests and tuning experiments).  A handle takes its settings
+ * from the ENVIRONMENT when it is created -- the variable names are the keys: "GULON_SCAN_FILTER" (0/1),
+ * "GULON_FILTER_MIN_RB", "GULON_FILTER_PERIOD", "GULON_FILTER_STAGE0", "GULON_FILTER_STAGE1", "GULON_FILTER_SAMPLE",
+ * "GULON_FILTER_CAP", "GULON_FILTER_NADD", "GULON_FILTER_BLOCKS", "GULON_FILTER_SHARED_STAGE1", "GULON_SCAN_BLOCKS",
+ * "GULON_SCAN_PRUNE", "GULON_SCAN_PRUNE_FROM" -- and this call changes them for ONE handle (and the contexts created
+ * from it afterwards); there is no process-wide setter.  Results never depend on them.
+ * "GULON_FILTER_ORDER" (default 1): an index of one-word codes (m <= 16) created while the environment's value is
+ * non-zero keeps a second, conflict-ordered copy of its codes for the filter kernel (+ 17 bytes per row; the value =
+ * rounds of the ordering); per handle 0 makes the filter read the plain copy again. */
 int32_t gulon_index_tuning(gulon_index *idx, const char *key, int32_t value);
 /* TopKHeap.merge semantics (TopKHeap.scala:44-53, used at Index.scala:279) under
  * the deterministic (distance, row id) order: merges `lists` partial lists per

@@ -20,7 +20,7 @@ for n in (65536, 131072, 262144, 524288, 1250000, 2500000):
     Q = torch.from_numpy(dm.get_rows(sample_rows(n, B, 0))).cuda()
     res = {}
     for name, min_rb in (("filter", 4), ("exact", 1 << 30)):
-        N.check(L.gulon_scan_tuning(b"GULON_FILTER_MIN_RB", min_rb))
+        g.tune_live(GULON_FILTER_MIN_RB=min_rb)
         for _ in range(3):
             N.check(L.gulon_index_batch_query_dev(ix._h, Q.data_ptr(), B, K, 0, n, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), of.data_ptr(), None))
         torch.cuda.synchronize()

@@ -38,8 +38,7 @@ def run(steps=5):
 
 
 def tune(**kw):
-    for key, v in kw.items():
-        N.check(L.gulon_scan_tuning(key.encode(), int(v)))
+    g.tune_live(**kw)
 
 
 base = run()

@@ -16,9 +16,7 @@ oracle.build()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 L = N.lib()
-for k_, v in dict(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE0=1, GULON_FILTER_STAGE1=2,
-                  GULON_FILTER_SAMPLE=512).items():
-    N.check(L.gulon_scan_tuning(k_.encode(), v))
+g.tune_live(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE0=1, GULON_FILTER_STAGE1=2, GULON_FILTER_SAMPLE=512)
 bad = 0
 for case in range(cases):
     m = int(rng.choice([16, 16, 16, 13, 9, 16]))

@@ -23,8 +23,7 @@ L = N.lib()
 
 
 def tune(**kw):
-    for k_, v in kw.items():
-        N.check(L.gulon_scan_tuning(k_.encode(), int(v)))
+    g.tune_live(**kw)
 
 
 bad = 0

@@ -85,6 +85,6 @@ ok = all(set(top_i[q][mine[q]].tolist()) <= set(pi[q].tolist()) for q in range(B
 res["rank0_list_covers_global_topk"] = bool(ok)
 for key in ("GULON_FILTER_SHARED_STAGE1",):
     for v in (0, 1):
-        N.check(N.lib().gulon_scan_tuning(key.encode(), v))
+        g.tune_live(**{key: v})
         res[f"shared_stage1_{v}_ms"] = run(True)
 print(json.dumps(res))

@@ -97,7 +97,7 @@ def test_c5_shape_train_encode_query_bit_exact(oracle, g, filt):
     rng = np.random.default_rng(11)
     Q = np.concatenate([X[:B // 2], (X[100:100 + B // 2] + 0.05 * rng.standard_normal((B // 2, d))).astype(np.float32)])
     L = g.native.lib()
-    g.native.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", filt))
+    g.native.check(L.gulon_index_tuning(index.vector_index._h, b"GULON_SCAN_FILTER", filt))
     try:
         res = index.batch_query(K, Q)
         tiles, redone = C.c_int32(-1), C.c_int32(-1)
@@ -106,7 +106,7 @@ def test_c5_shape_train_encode_query_bit_exact(oracle, g, filt):
         assert (tiles.value > 0) == bool(filt), (filt, tiles.value)
         sub = index.vector_index.batch_query(K, Q, 777, 33333)
     finally:
-        g.native.check(L.gulon_scan_tuning(b"GULON_SCAN_FILTER", 1))
+        g.native.check(L.gulon_index_tuning(index.vector_index._h, b"GULON_SCAN_FILTER", 1))
     oi, od, oc = oracle.pq_batch_query(idx, d, k, cents, Q, K)
     si, sd, sc = oracle.pq_batch_query(idx, d, k, cents, Q, K, 777, 33333)
     for q in range(B):

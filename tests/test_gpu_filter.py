@@ -26,20 +26,27 @@ def g():
 
 @pytest.fixture
 def tune(g):
+    """Knobs for the handles created from now on (the environment) and for the ones already open (gulon_index_tuning)."""
+    import os
+    before = {k: os.environ.get(k) for k in DEFAULTS}
+    g.tune_live(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE0=1, GULON_FILTER_STAGE1=2,
+                GULON_FILTER_SAMPLE=512)
+    yield g.tune_live
+    g.tune_live(**DEFAULTS)
+    for k, v in before.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_tuning_rejects_unknown_key(oracle, g):
     from gulon_amd import native as N
-
-    def set_(**kw):
-        for k, v in kw.items():
-            N.check(N.lib().gulon_scan_tuning(k.encode(), int(v)))
-    set_(GULON_FILTER_MIN_RB=4, GULON_FILTER_PERIOD=8, GULON_FILTER_STAGE0=1, GULON_FILTER_STAGE1=2,
-         GULON_FILTER_SAMPLE=512)
-    yield set_
-    set_(**DEFAULTS)
-
-
-def test_tuning_rejects_unknown_key(g):
-    from gulon_amd import native as N
-    assert N.lib().gulon_scan_tuning(b"GULON_NO_SUCH_KNOB", 1) != 0
+    cents, idx, pq, enc = _make(oracle, g, 300, 8, 2, 4, seed=1)
+    ix = g.PQIndex(pq, enc)
+    assert N.lib().gulon_index_tuning(ix._h, b"GULON_NO_SUCH_KNOB", 1) != 0
+    assert N.lib().gulon_index_tuning(ix._h, b"GULON_FILTER_CAP", 128) == 0
+    ix.close()
 
 
 @pytest.mark.parametrize("nadd", [2, 4])

@@ -23,14 +23,18 @@ def g():
 
 @pytest.fixture
 def tune(g):
-    from gulon_amd import native as N
-
-    def set_(**kw):
-        for k, v in kw.items():
-            N.check(N.lib().gulon_scan_tuning(k.encode(), int(v)))
-    yield set_
-    set_(GULON_FILTER_MIN_RB=512, GULON_FILTER_PERIOD=128, GULON_FILTER_STAGE0=0, GULON_FILTER_STAGE1=10,
-         GULON_FILTER_SAMPLE=65536, GULON_FILTER_SHARED_STAGE1=-1)
+    """Knobs for the handles created from now on (the environment) and for the ones already open (gulon_index_tuning)."""
+    import os
+    defaults = dict(GULON_FILTER_MIN_RB=512, GULON_FILTER_PERIOD=128, GULON_FILTER_STAGE0=0, GULON_FILTER_STAGE1=10,
+                    GULON_FILTER_SAMPLE=65536, GULON_FILTER_SHARED_STAGE1=-1)
+    before = {k: os.environ.get(k) for k in defaults}
+    yield g.tune_live
+    g.tune_live(**defaults)
+    for k, v in before.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 class ThreadGroup:

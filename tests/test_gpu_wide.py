@@ -200,7 +200,9 @@ def test_wide_filter_sharded_equals_unsharded(g, n, d, m, k, B, K):
     from test_gpu_shared_bounds import _same, sharded_query
     import ctypes as C
     from gulon_amd import native as N
-    N.check(N.lib().gulon_scan_tuning(b"GULON_FILTER_MIN_RB", 4))
+    import os
+    before = os.environ.get("GULON_FILTER_MIN_RB")
+    g.tune_live(GULON_FILTER_MIN_RB=4)
     try:
         rng = np.random.default_rng(8)
         cents = rng.standard_normal(k * d).astype(np.float32)
@@ -212,4 +214,8 @@ def test_wide_filter_sharded_equals_unsharded(g, n, d, m, k, B, K):
         full = g.PQIndex(pq, enc).batch_query_raw(K, Q)
         _same(sharded_query(g, pq, enc, n, 3, Q, K), full)
     finally:
-        N.check(N.lib().gulon_scan_tuning(b"GULON_FILTER_MIN_RB", 512))
+        g.tune_live(GULON_FILTER_MIN_RB=512)
+        if before is None:
+            os.environ.pop("GULON_FILTER_MIN_RB", None)
+        else:
+            os.environ["GULON_FILTER_MIN_RB"] = before
