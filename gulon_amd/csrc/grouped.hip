@@ -1362,7 +1362,8 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       // every searched row through this kernel
       const bool by_group = gx->gfilter.built && group_filter_applies(ix->m, ix->m_pad, ix->ng, ix->vec, ix->k, ix->d) &&
                             nn_stride > GF_SAMPLE_GROUPS && B <= 65535 &&   // (a grid's y extent carries the query)
-                            (long long)B * nn_stride <= (1ll << 28);        // (the pair lists: 1 GiB at most)
+                            (long long)B * nn_stride <= (1ll << 28) &&      // (the pairs' tiles)
+                            (long long)B * g <= (1ll << 27);                // (the groups' query lists, room for all: 512 MiB at most)
       if (!by_group)   // (the by-group path builds the tables where it quantizes them)
         hipLaunchKernelGGL(gq_ptables, dim3(ix->m_pad, B), dim3(256), 0, st, ix->cents.p, ix->from.p, ix->sdim.p, ix->d, ix->m,
                            ix->m_pad, ix->k, dQ, gx->ptab.p);

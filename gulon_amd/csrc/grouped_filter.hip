@@ -108,9 +108,8 @@ __global__ void gf_gnorm(const float *__restrict__ gcent, int g, int d, float *_
 }
 
 // ---- per batch: for every group the queries that search it -------------------------------------------
-// goff: first pair of every group, toff: first tile (GF_QT pairs) of every group; meta[0] = tiles
-__global__ __launch_bounds__(1024) void gf_scan(const int *__restrict__ gcnt, int g, int *__restrict__ goff, int *__restrict__ toff,
-                                                int *__restrict__ cursor, int *__restrict__ meta) {
+// toff: first tile (GF_QT pairs) of every group; meta[0] = tiles, meta[1] = pairs
+__global__ __launch_bounds__(1024) void gf_scan(const int *__restrict__ gcnt, int g, int *__restrict__ toff, int *__restrict__ meta) {
   __shared__ int sa[1024], sb[1024];
   const int tid = threadIdx.x, per = (g + 1023) / 1024;
   const int lo = min(g, tid * per), hi = min(g, lo + per);
@@ -124,37 +123,31 @@ __global__ __launch_bounds__(1024) void gf_scan(const int *__restrict__ gcnt, in
     sa[tid] += va; sb[tid] += vb;
     __syncthreads();
   }
-  int ea = sa[tid] - a, eb = sb[tid] - b;
+  int eb = sb[tid] - b;
   for (int c = lo; c < hi; c++) {
-    goff[c] = ea; toff[c] = eb; cursor[c] = 0;
-    ea += gcnt[c]; eb += (gcnt[c] + GF_QT - 1) / GF_QT;
+    toff[c] = eb;
+    eb += (gcnt[c] + GF_QT - 1) / GF_QT;
   }
-  if (tid == 1023) { goff[g] = sa[1023]; toff[g] = sb[1023]; meta[0] = sb[1023]; meta[1] = sa[1023]; }
+  if (tid == 1023) { toff[g] = sb[1023]; meta[0] = sb[1023]; meta[1] = sa[1023]; }
 }
 
 // (Leaving out the pairs whose budget is negative even for the group's best row -- threshold - table minima -
 // (|q - g|^2 - |g|^2 + the group's smallest row norm) < 0 -- was tried: under 1 % of the pairs at 10 M rows /
-// LimitGroups(500), for two scattered loads per pair.)
-__global__ void gf_fill(const int *__restrict__ nn, int stride, const int *__restrict__ nn_cnt, const int *__restrict__ bounds,
-                        const int *__restrict__ goff, int *__restrict__ cursor, int *__restrict__ pairs) {
-  const int q = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nn_cnt[q]) return;
-  const int c = nn[(size_t)q * stride + t];
-  if (bounds[c + 1] > bounds[c]) pairs[goff[c] + atomicAdd(&cursor[c], 1)] = q;
-}
+// LimitGroups(500), for two scattered loads per pair.  The lists themselves: every group has room for all B queries
+// (pairs[c][B]), so a query is appended where it is counted, in gf_quant -- no offsets, no second pass over the pairs.)
 
 // everything a tile's workgroup needs to start, in one record (one scalar round trip instead of four dependent ones)
-__global__ void gf_tiles(const int *__restrict__ goff, const int *__restrict__ toff, int g, const int *__restrict__ bounds,
+__global__ void gf_tiles(const int *__restrict__ gcnt, const int *__restrict__ toff, int g, int B, const int *__restrict__ bounds,
                          const float *__restrict__ xnlo, const int *__restrict__ pairs, GfTile *__restrict__ tiles) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= g) return;
-  const int t0 = toff[c], t1 = toff[c + 1];
+  const int t0 = toff[c], t1 = toff[c + 1], cnt = gcnt[c];
   for (int t = t0; t < t1; t++) {
-    const int first = goff[c] + (t - t0) * GF_QT;
+    const int first = (t - t0) * GF_QT;
     GfTile T;
-    T.c = c; T.nq = min(GF_QT, goff[c + 1] - first); T.r0 = bounds[c]; T.r1 = bounds[c + 1]; T.xl = xnlo[c];
+    T.c = c; T.nq = min(GF_QT, cnt - first); T.r0 = bounds[c]; T.r1 = bounds[c + 1]; T.xl = xnlo[c];
     T.pad[0] = T.pad[1] = T.pad[2] = 0;
-    for (int i = 0; i < GF_QT; i++) T.qid[i] = pairs[first + min(i, T.nq - 1)];
+    for (int i = 0; i < GF_QT; i++) T.qid[i] = pairs[(size_t)c * B + first + min(i, T.nq - 1)];
     tiles[t] = T;
   }
 }
@@ -171,7 +164,7 @@ __global__ __launch_bounds__(256) void gf_quant(float *__restrict__ P /* out: th
                                                 const int *__restrict__ nn, int stride, const int *__restrict__ nn_cnt,
                                                 const uint8_t *__restrict__ codes, int ng, const float *__restrict__ xnorm,
                                                 const float *__restrict__ gcent, const int *__restrict__ bounds,
-                                                float xnmax, float xn_step, int *__restrict__ gcnt,
+                                                float xnmax, float xn_step, int *__restrict__ gcnt, int *__restrict__ pairs, int B,
                                                 uint8_t *__restrict__ qb, float *__restrict__ qs) {
   extern __shared__ float gq_sm[];             // d query coordinates, the query's P table (m_pad x 256), GF_SAMPLE_ROWS values
   float *qv = gq_sm, *tab = gq_sm + d, *vals = tab + m_pad * 256;
@@ -274,7 +267,7 @@ __global__ __launch_bounds__(256) void gf_quant(float *__restrict__ P /* out: th
   float mb = INFINITY;
   for (int t = tid; t < ngroups; t += 256) {
     const int c = nn[(size_t)q * stride + t];
-    if (bounds[c + 1] > bounds[c]) atomicAdd(&gcnt[c], 1);                // the group's list of queries grows by this one
+    if (bounds[c + 1] > bounds[c]) pairs[(size_t)c * B + atomicAdd(&gcnt[c], 1)] = q;   // the group's list of queries (room for all B) grows by this one
     const float base = (cdist[(size_t)q * g + c] - gnorm[c]) + xnlo[c];   // + the group's smallest row norm
     bad = bad || !(fabsf(base) < INFINITY);
     mb = fminf(mb, base);
@@ -637,8 +630,8 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
   const size_t pairs_max = (size_t)B * nn_stride;
   const size_t tiles_max = pairs_max / GF_QT + (size_t)g + 1;
   GULON_UNSUPPORTED(tiles_max >= (1ull << 31), "too many (query, group) pairs");
-  gf.gcnt.ensure((size_t)g + 1); gf.goff.ensure((size_t)g + 1); gf.toff.ensure((size_t)g + 1); gf.cursor.ensure((size_t)g + 1);
-  gf.pairs.ensure(pairs_max); gf.tiles.ensure(tiles_max); gf.meta.ensure(4); gf.qcnt.ensure((size_t)B);
+  gf.gcnt.ensure((size_t)g + 1); gf.toff.ensure((size_t)g + 1);
+  gf.pairs.ensure((size_t)g * B); gf.tiles.ensure(tiles_max); gf.meta.ensure(4); gf.qcnt.ensure((size_t)B);
   gf.qb.ensure((size_t)B * GF_NT * 256); gf.qs.ensure((size_t)B * 4); gf.queue.ensure((size_t)B * GF_CAP);
   HIP_CHECK(hipMemsetAsync(gf.gcnt.p, 0, sizeof(int) * ((size_t)g + 1), st));
   HIP_CHECK(hipMemsetAsync(gf.qcnt.p, 0, sizeof(int) * (size_t)B, st));
@@ -647,13 +640,10 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
     auto kern = vec == 16 ? gf_quant<16> : gf_quant<4>;
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
     hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, pq_cents, from, sdim, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
-                       nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.gcnt.p, gf.qb.p, gf.qs.p);
+                       nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.gcnt.p, gf.pairs.p, B, gf.qb.p, gf.qs.p);
   }
-  const dim3 pg(ceil_div(nn_stride, 256), B);
-  hipLaunchKernelGGL(gf_scan, dim3(1), dim3(1024), 0, st, gf.gcnt.p, g, gf.goff.p, gf.toff.p, gf.cursor.p, gf.meta.p);
-  hipLaunchKernelGGL(gf_fill, pg, dim3(256), 0, st, nn, nn_stride, nn_cnt, bounds, gf.goff.p, gf.cursor.p,
-                     gf.pairs.p);
-  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, 256)), dim3(256), 0, st, gf.goff.p, gf.toff.p, g, bounds, gf.xnlo.p, gf.pairs.p,
+  hipLaunchKernelGGL(gf_scan, dim3(1), dim3(1024), 0, st, gf.gcnt.p, g, gf.toff.p, gf.meta.p);
+  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, 256)), dim3(256), 0, st, gf.gcnt.p, gf.toff.p, g, B, bounds, gf.xnlo.p, gf.pairs.p,
                      gf.tiles.p);
   HIP_CHECK(hipGetLastError());
   const size_t lds_f = sizeof(uint4) * GF_NT * 256;
