@@ -578,11 +578,25 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     auto scan4 = [&](const f32x16 &acc, int r0, float &p, float &mband) {
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
+#ifdef GULON_BF16_SCALAR_SUB
         const float k0 = acc[r0 + e], k1 = acc[r0 + e + 1];
         const float q0 = fmin2(p, k0), q1 = fmin2(q0, k1);
         const float d0 = k0 - p, d1 = k1 - q0;
         asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
         p = q1;
+#else
+        // both differences (key - the running minimum before it) in ONE packed subtraction: the two keys are
+        // neighbouring accumulator registers, the two minima are kept as a register pair
+        const f32x2 kk = {acc[r0 + e], acc[r0 + e + 1]};
+        f32x2 pp;
+        pp.x = p;
+        pp.y = fmin2(p, kk.x);
+        const float q1 = fmin2(pp.y, kk.y);
+        f32x2 dd;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dd) : "v"(kk), "v"(pp));
+        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(dd.x), "v"(dd.y));
+        p = q1;
+#endif
       }
     };
     // after a block: the row's running minimum and where it sits.  lo / hi = the minima of the block's first and
