@@ -1440,7 +1440,7 @@ void kmeans_train_batch(const float *dX, int n, int ld, int np, const int *from,
     // where that fits beside the slices and the assign's packed operands with a quarter of the device's memory to spare
     size_t need = 0, free_b = 0, total_b = 0;
     for (int p = 0; p < np; p++) need += (size_t)stream_padded_rows(n) * (8 * (size_t)((sdim[p] + 1) / 2) + 4);
-    for (int p = 0; p < np; p++) need += (size_t)n * (4 * (size_t)sdim[p] + 96 + 16);   // (the buffers allocated below either way)
+    for (int p = 0; p < np; p++) need += (size_t)n * (4 * (size_t)sdim[p] + 160 + 16);   // (the buffers allocated below either way)
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     if (need + total_b / 4 > free_b) stream_update = false;
   }

@@ -17,6 +17,7 @@ struct PackedSlice {
   DevBuf<float> xn;
   int n = 0, from = 0, s = 0, T = 0;
   bool split = false;
+  int words = 0;   // split: 0 = three pieces per lane and tile, else that many compact operand words (s <= 13: kmeans_mfma.hip)
 };
 
 // one problem of a batched KMeans.fromAssignment (kmeans.hip)

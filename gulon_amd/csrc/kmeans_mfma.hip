@@ -414,6 +414,46 @@ __device__ __forceinline__ void pack8(const float (&v)[8], uint4 &o1, uint4 &o2,
   o3 = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
 }
 
+// The compact operand layout (s <= 13).  The six piece products (a3,b1) (a1,b3) (a2,b2) (a2,b1) (a1,b2) (a1,b1) need
+// 6 s of a matrix instruction's K slots, not 6 x 16: product t takes the slots [t s, (t + 1) s) of a virtual K of 16 NA
+// (NA = ceil(6 s / 16) operand words per lane: 3 for s <= 8, 4 for s <= 10, 5 for s <= 13), piece pa[t] of -2 c on the A
+// side, piece pb[t] of x on the B side, zeros behind the last product -- NA matrix instructions per tile and centroid
+// block instead of six (config 3, s = 9 / 10: four).  Slots are summed smallest products first, as before.
+__host__ __device__ constexpr int split_words(int s) { return s <= 8 ? 3 : s <= 10 ? 4 : s <= 13 ? 5 : 6; }
+// the operand word (8 slots) of lane half `half` of instruction u: get(e) = element e of the row / centroid
+template <typename Get>
+__device__ __forceinline__ uint4 compact_word(Get get, int s, int u, int half, bool a_side) {
+  unsigned h[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int g = 16 * u + 8 * half + j;
+    const int t = g / s, e = g - t * s;
+    unsigned p1 = 0, p2 = 0, p3 = 0;
+    if (t < 6) split3(get(e), p1, p2, p3);
+    // pa = {2, 0, 1, 1, 0, 0}, pb = {0, 2, 1, 0, 1, 0}
+    const int piece = a_side ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
+    h[j] = piece == 0 ? p1 : piece == 1 ? p2 : p3;
+  }
+  return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+// rows -> NA compact operand words per (tile, lane) + |x|^2 per row
+__global__ void pack_slice_compact(const float *__restrict__ X, int n, int ld, int from, int s, int na, long long nlanes,
+                                   uint4 *__restrict__ out, float *__restrict__ xn) {
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 >= nlanes) return;
+  const int l = (int)(t0 & 63);
+  const long long tile = t0 >> 6;
+  const long long row = tile * 32 + (l & 31);
+  auto get = [&](int e) { return row < n ? X[(size_t)row * ld + from + e] : 0.f; };
+  for (int u = 0; u < na; u++) out[(tile * na + u) * 64 + l] = compact_word(get, s, u, l >> 5, false);
+  if (l < 32 && row < n) {
+    float acc = 0.f;
+    for (int e = 0; e < s; e++) { const float x = X[(size_t)row * ld + from + e]; acc += x * x; }
+    xn[row] = acc;
+  }
+}
+
 // rows -> three bf16 operand pieces per (tile, lane) + |x|^2 per row
 __global__ void pack_slice_split(const float *__restrict__ X, int n, int ld, int from, int s, long long nlanes,
                                  uint4 *__restrict__ out, float *__restrict__ xn) {
@@ -441,9 +481,14 @@ __global__ void pack_slice_split(const float *__restrict__ X, int n, int ld, int
 // A operands: -2 c in three bf16 pieces [kb][piece][64 lanes]; offsets (1e38 beyond k) and max |c|^2 as before
 __global__ void pack_centroids_split(const float *__restrict__ C, const float *__restrict__ off, int k, int s, int nkb,
                                      uint4 *__restrict__ apack, float *__restrict__ offp,
-                                     unsigned *__restrict__ cmax2_bits) {
+                                     unsigned *__restrict__ cmax2_bits, int na /* 0: three pieces; else compact words */) {
   const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t0 < nkb * 64) {
+  if (t0 < nkb * 64 && na) {           // the compact layout (same centroid order over the rows of the A operand)
+    const int l = t0 & 63, kb = t0 >> 6, i = l & 31;
+    const int c = kb * 32 + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+    auto get = [&](int e) { return c < k ? -2.0f * C[(size_t)c * s + e] : 0.f; };
+    for (int u = 0; u < na; u++) apack[(kb * na + u) * 64 + l] = compact_word(get, s, u, l >> 5, true);
+  } else if (t0 < nkb * 64) {
     const int l = t0 & 63, kb = t0 >> 6;
     // Which centroid sits in which row of the A operand is ours to choose.  The 32x32 result leaves a lane with rows
     // 8g + 4h + t (g, t = 0..3; h = lane / 32): row i = 8g + 4h + t carries centroid 16h + 4g + t of the block, so that
@@ -469,6 +514,9 @@ __global__ void pack_centroids_split(const float *__restrict__ C, const float *_
 
 // probe != nullptr (one workgroup, selftest): the raw d' of the first tile pair against centroid block 0 go to
 // probe[64 rows][32 centroids] and nothing else is written
+// NA operand words per lane, tile and centroid block: three pieces and six products of pairs of them (COMPACT = false),
+// or NA compact words, one matrix instruction each (see compact_word)
+template <int NA, bool COMPACT>
 __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 *__restrict__ xq, const float *__restrict__ xn, int n,
                                                    long long npairs, const uint4 *__restrict__ apack,
                                                    const float *__restrict__ offp, int nkb,
@@ -476,10 +524,11 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
                                                    int *__restrict__ assign, int *__restrict__ flag_rows,
                                                    unsigned *__restrict__ flag_count, float *__restrict__ probe) {
   extern __shared__ float sm[];
-  uint4 *sA = reinterpret_cast<uint4 *>(sm);                       // [nkb][3][64]
-  float *sOff = sm + (size_t)nkb * 3 * 64 * 4;                     // 2 copies of nkb*32
+  constexpr int NMF = COMPACT ? 2 * NA : 12;                       // matrix instructions per block and tile pair
+  uint4 *sA = reinterpret_cast<uint4 *>(sm);                       // [nkb][NA][64]
+  float *sOff = sm + (size_t)nkb * NA * 64 * 4;                     // 2 copies of nkb*32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < nkb * 3 * 64; e += 256) sA[e] = apack[e];
+  for (int e = tid; e < nkb * NA * 64; e += 256) sA[e] = apack[e];
   for (int e = tid; e < nkb * 32; e += 256) { sOff[e] = offp[e]; sOff[nkb * 32 + e] = offp[e]; }
   __syncthreads();
   const float cmax2 = __uint_as_float(*cmax2_bits);
@@ -488,15 +537,15 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
 
   // B operands of the NEXT tile pair are loaded while the current one is in the matrix pipe
   const long long pstride = (long long)gridDim.x * 4;
-  uint4 nb[2][3];
+  uint4 nb[2][NA];
   float nxn;
   auto load_pair = [&](long long pp) {
     const long long pc = min(pp, npairs - 1);                      // clamped: always valid
-    const uint4 *px = xq + (size_t)(2 * pc) * 3 * 64 + lane;
+    const uint4 *px = xq + (size_t)(2 * pc) * NA * 64 + lane;
 #pragma unroll
     for (int y = 0; y < 2; y++)
 #pragma unroll
-      for (int p = 0; p < 3; p++) nb[y][p] = px[(size_t)(y * 3 + p) * 64];
+      for (int p = 0; p < NA; p++) nb[y][p] = px[(size_t)(y * NA + p) * 64];
     const long long row = pc * 64 + lane;
     nxn = row < n ? xn[row] : 0.f;
   };
@@ -504,9 +553,9 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
   f32x16 ax, ay, bx2, by2;
   bool have_acc = false;             // (ax, ay) already hold this pair's first block
   for (long long pp = (long long)blockIdx.x * 4 + wave; pp < npairs; pp += pstride) {
-    bf16x8 bx[3], by[3];
+    bf16x8 bx[NA], by[NA];
 #pragma unroll
-    for (int p = 0; p < 3; p++) { bx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); by[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
+    for (int p = 0; p < NA; p++) { bx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); by[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
     const float nx = nxn;            // |x|^2 of the row this lane answers for (row pp*64 + lane)
     load_pair(pp + pstride);
     // 2E band (see file header); non-finite inputs make it NaN => row flagged below
@@ -536,7 +585,7 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     };
     Scan sx{FLT_MAX, INFINITY, -1}, sy{FLT_MAX, INFINITY, -1};
 
-    auto init_block = [&](int kb, f32x16 &ax, f32x16 &ay, bf16x8 (&a)[3]) {
+    auto init_block = [&](int kb, f32x16 &ax, f32x16 &ay, bf16x8 (&a)[NA]) {
       const float4 *so = reinterpret_cast<const float4 *>(sOff + kb * 32 + 16 * half);
       const float4 *so2 = reinterpret_cast<const float4 *>(sOff + nkb * 32 + kb * 32 + 16 * half);
 #pragma unroll
@@ -547,15 +596,16 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
         ay[4 * g + 0] = o2.x; ay[4 * g + 1] = o2.y; ay[4 * g + 2] = o2.z; ay[4 * g + 3] = o2.w;
       }
 #pragma unroll
-      for (int p = 0; p < 3; p++) a[p] = __builtin_bit_cast(bf16x8, sA[(kb * 3 + p) * 64 + lane]);
+      for (int p = 0; p < NA; p++) a[p] = __builtin_bit_cast(bf16x8, sA[(kb * NA + p) * 64 + lane]);
     };
     // the six piece products, smallest first: (a3,b1) (a1,b3) (a2,b2) (a2,b1) (a1,b2) (a1,b1); MFMA m: product m / 2,
     // tile X (even m) or Y (odd m)
-    auto one_mfma = [&](int m, f32x16 &ax, f32x16 &ay, const bf16x8 (&a)[3]) {
+    auto one_mfma = [&](int m, f32x16 &ax, f32x16 &ay, const bf16x8 (&a)[NA]) {
       constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
       const int t = m >> 1;
-      if (m & 1) ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], by[pb[t]], ay, 0, 0, 0);
-      else ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], bx[pb[t]], ax, 0, 0, 0);
+      const int ia = COMPACT ? t : pa[t], ib = COMPACT ? t : pb[t];
+      if (m & 1) ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], by[ib], ay, 0, 0, 0);
+      else ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], bx[ib], ax, 0, 0, 0);
     };
     auto fmin3 = [](float a, float b, float c) {
       float r;
@@ -574,30 +624,34 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       const float m4 = fmin3(acc[12], acc[13], acc[14]);
       return fmin2(fmin3(m0, m1, m2), fmin3(m3, m4, acc[15]));
     };
-    // pass 2 over keys r0 .. r0 + 3 of one tile, from running minimum p
-    auto scan4 = [&](const f32x16 &acc, int r0, float &p, float &mband) {
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
+    // pass 2 over keys r, r + 1 of BOTH tiles, from running minima (px, py).  The two tiles' chains are written side by
+    // side: every instruction here is inline assembly, and the compiler puts a wait state between an inline-assembly
+    // instruction and a consumer that follows it directly (it has to assume a destination-select forwarding hazard) --
+    // one chain at a time cost 35 s_nop per block.
+    // Both differences of a tile (key - the running minimum before it) are ONE packed subtraction: the two keys are
+    // neighbouring accumulator registers, the two minima are kept as a register pair.
+    auto scan2 = [&](const f32x16 &cx, const f32x16 &cy, int r, float &px, float &py, float &mbx, float &mby) {
 #ifdef GULON_BF16_SCALAR_SUB
-        const float k0 = acc[r0 + e], k1 = acc[r0 + e + 1];
-        const float q0 = fmin2(p, k0), q1 = fmin2(q0, k1);
-        const float d0 = k0 - p, d1 = k1 - q0;
-        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(d0), "v"(d1));
-        p = q1;
+      const float kx0 = cx[r], kx1 = cx[r + 1], ky0 = cy[r], ky1 = cy[r + 1];
+      const float qx0 = fmin2(px, kx0), qy0 = fmin2(py, ky0), qx1 = fmin2(qx0, kx1), qy1 = fmin2(qy0, ky1);
+      const float dx0 = kx0 - px, dx1 = kx1 - qx0, dy0 = ky0 - py, dy1 = ky1 - qy0;
+      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mbx) : "v"(mbx), "v"(dx0), "v"(dx1));
+      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mby) : "v"(mby), "v"(dy0), "v"(dy1));
+      px = qx1; py = qy1;
 #else
-        // both differences (key - the running minimum before it) in ONE packed subtraction: the two keys are
-        // neighbouring accumulator registers, the two minima are kept as a register pair
-        const f32x2 kk = {acc[r0 + e], acc[r0 + e + 1]};
-        f32x2 pp;
-        pp.x = p;
-        pp.y = fmin2(p, kk.x);
-        const float q1 = fmin2(pp.y, kk.y);
-        f32x2 dd;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dd) : "v"(kk), "v"(pp));
-        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mband) : "v"(mband), "v"(dd.x), "v"(dd.y));
-        p = q1;
+      const f32x2 kx = {cx[r], cx[r + 1]}, ky = {cy[r], cy[r + 1]};
+      f32x2 ppx, ppy, ddx, ddy;
+      ppx.x = px; ppy.x = py;
+      ppx.y = fmin2(px, kx.x);
+      ppy.y = fmin2(py, ky.x);
+      const float qx = fmin2(ppx.y, kx.y);
+      const float qy = fmin2(ppy.y, ky.y);
+      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ddx) : "v"(kx), "v"(ppx));
+      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ddy) : "v"(ky), "v"(ppy));
+      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mbx) : "v"(mbx), "v"(ddx.x), "v"(ddx.y));
+      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mby) : "v"(mby), "v"(ddy.x), "v"(ddy.y));
+      px = qx; py = qy;
 #endif
-      }
     };
     // after a block: the row's running minimum and where it sits.  lo / hi = the minima of the block's first and
     // second 16 centroids (both lanes of a row hold both after the exchange); branch-free
@@ -614,15 +668,20 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     // (nx_, ny_).  Twelve matrix instructions, twelve slices of vector work between them: a matrix instruction
     // that depends on the one two slices back (same accumulator) never waits, and neither does the wave's issue.
     auto step = [&](auto next_tag, int kb, int kb_next, f32x16 &cx, f32x16 &cy, f32x16 &nx_, f32x16 &ny_,
-                    const bf16x8 (&nbx)[3], const bf16x8 (&nby)[3]) {
+                    const bf16x8 (&nbx)[NA], const bf16x8 (&nby)[NA]) {
       constexpr bool NEXT = decltype(next_tag)::value;
-      bf16x8 a[3];
-      auto mf = [&](int m) {
+      bf16x8 a[NA];
+      // twelve slices of vector work; slice `site` is followed by matrix instruction ceil(site NMF / 12) if that differs
+      // from the next slice's (NMF = 12: every slice; 8: slices 0 1 3 4 6 7 9 10)
+      auto mf = [&](int site) {
         if (!NEXT) return;
+        const int m = (site * NMF + 11) / 12;
+        if ((((site + 1) * NMF + 11) / 12) == m) return;
         constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
         const int t = m >> 1;
-        if (m & 1) ny_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], nby[pb[t]], ny_, 0, 0, 0);
-        else nx_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], nbx[pb[t]], nx_, 0, 0, 0);
+        const int ia = COMPACT ? t : pa[t], ib = COMPACT ? t : pb[t];
+        if (m & 1) ny_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], nby[ib], ny_, 0, 0, 0);
+        else nx_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], nbx[ib], nx_, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       if (NEXT) init_block(kb_next, nx_, ny_, a);
@@ -648,9 +707,9 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       // pass 2
 #pragma unroll
       for (int h = 0; h < 4; h++) {
-        scan4(cx, 4 * h, px, sx.mband);
+        scan2(cx, cy, 4 * h, px, py, sx.mband, sy.mband);
         mf(3 + 2 * h);
-        scan4(cy, 4 * h, py, sy.mband);
+        scan2(cx, cy, 4 * h + 2, px, py, sx.mband, sy.mband);
         mf(4 + 2 * h);
       }
       close_block(sx, kb, lox, hix);
@@ -661,10 +720,10 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     using No = std::integral_constant<bool, false>;
 
     if (!have_acc) {               // the pair's first block (a pair's last step leaves it ready: see below)
-      bf16x8 a0[3];
+      bf16x8 a0[NA];
       init_block(0, ax, ay, a0);
 #pragma unroll
-      for (int m = 0; m < 12; m++) one_mfma(m, ax, ay, a0);
+      for (int m = 0; m < NMF; m++) one_mfma(m, ax, ay, a0);
     }
     if (probe) {   // selftest: raw distances of (first 64 rows) x (centroid block 0)
       if (blockIdx.x == 0 && wave == 0) {
@@ -678,7 +737,7 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       return;
     }
     // the NEXT pair's B operands (requested at the top of this iteration, one whole pair ahead)
-    bf16x8 fx[3], fy[3];
+    bf16x8 fx[NA], fy[NA];
     const bool more = pp + pstride < npairs;
     int kb = 0;
     for (; kb + 2 < nkb; kb += 2) {
@@ -690,7 +749,7 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       // an even number of blocks: the last step's idle accumulators are (ax, ay) again -- the next pair's first block
       // goes there, its twelve matrix instructions between this block's vector work instead of in a row of their own
 #pragma unroll
-      for (int p = 0; p < 3; p++) { fx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); fy[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
+      for (int p = 0; p < NA; p++) { fx[p] = __builtin_bit_cast(bf16x8, nb[0][p]); fy[p] = __builtin_bit_cast(bf16x8, nb[1][p]); }
       if (more) { step(Yes{}, kb + 1, 0, bx2, by2, ax, ay, fx, fy); have_acc = true; }
       else { step(No{}, kb + 1, 0, bx2, by2, ax, ay, fx, fy); have_acc = false; }
     } else {
@@ -726,10 +785,16 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
   }
 }
 
+// operand words per lane, tile and centroid block: 0 = three pieces (six matrix instructions), else the compact layout
+static int split_compact_words(int s) {
+  static const bool off = [] { const char *e = getenv("GULON_KMEANS_COMPACT"); return e && atoi(e) == 0; }();   // A/B knob
+  return !off && split_words(s) < 6 ? split_words(s) : 0;
+}
 static bool mfma_split(int s, int k) {
   static const bool off = getenv("GULON_KMEANS_F32_MFMA") != nullptr;   // A/B knob: the fp32 matrix instruction instead
   const int nkb = (k + 31) / 32;
-  return !off && s >= 1 && s <= 16 && ((size_t)nkb * (3 * 64 * 16 + 64 * 4)) <= 60 * 1024;
+  const int na = split_compact_words(s) ? split_compact_words(s) : 3;
+  return !off && s >= 1 && s <= 16 && ((size_t)nkb * (na * 64 * 16 + 64 * 4)) <= 60 * 1024;
 }
 static float split_errk(int s) {
   // band = 2.1 * E + key perturbation (see the kernel's header): E / S = [(s+1) + 6 (s+2)] 2^-24 + 2^-22.9
@@ -769,10 +834,15 @@ void pack_slice(const float *dX, int n, int ld, int from, int s, int k, PackedSl
   ntile = (ntile + 1) / 2 * 2;   // whole pairs
   if (ps.split) {
     const long long nlanes = ntile * 64;
-    ps.xq.ensure((size_t)std::max<long long>(nlanes * 3 * 4, 4));     // uint4 per (tile, piece, lane)
+    ps.words = split_compact_words(s);
+    const int na = ps.words ? ps.words : 3;
+    ps.xq.ensure((size_t)std::max<long long>(nlanes * na * 4, 4));    // uint4 per (tile, piece or word, lane)
     ps.xn.ensure((size_t)std::max<long long>(ntile * 32, 1));
     GULON_UNSUPPORTED(nlanes >= (1ll << 32), "slice of %lld rows: a dispatch carries fewer than 2^32 work-items", (long long)n);
-    if (n > 0)
+    if (n > 0 && ps.words)
+      hipLaunchKernelGGL(pack_slice_compact, dim3((unsigned)ceil_div(nlanes, 256LL)), dim3(256), 0, st, dX, n, ld, from, s, na,
+                         nlanes, reinterpret_cast<uint4 *>(ps.xq.p), ps.xn.p);
+    else if (n > 0)
       hipLaunchKernelGGL(pack_slice_split, dim3((unsigned)ceil_div(nlanes, 256LL)), dim3(256), 0, st, dX, n, ld, from, s,
                          nlanes, reinterpret_cast<uint4 *>(ps.xq.p), ps.xn.p);
     HIP_CHECK(hipGetLastError());
@@ -793,9 +863,11 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
                         hipStream_t st) {
   const int s = ps.s, T = ps.T, n = ps.n;
   const int nkb = (k + 31) / 32;
-  GULON_REQUIRE(T == mfma_kernel_T(s, k) && ps.split == mfma_split(s, k), "packed slice was laid out for another kernel (T = %d)", T);
+  GULON_REQUIRE(T == mfma_kernel_T(s, k) && ps.split == mfma_split(s, k) && (!ps.split || ps.words == split_compact_words(s)),
+                "packed slice was laid out for another kernel (T = %d)", T);
   if (ps.split) {
-    ws.apack.ensure((size_t)nkb * 3 * 64 * 4);
+    const int na = ps.words ? ps.words : 3;
+    ws.apack.ensure((size_t)nkb * na * 64 * 4);
     ws.offp.ensure((size_t)nkb * 32);
     ws.cmax2.ensure(1);
     ws.flag_rows.ensure((size_t)std::max(n, 1));
@@ -803,12 +875,14 @@ void assign_mfma_filter(KmeansWorkspace &ws, const PackedSlice &ps, const float 
     HIP_CHECK(hipMemsetAsync(ws.cmax2.p, 0, sizeof(unsigned), st));
     HIP_CHECK(hipMemsetAsync(ws.flag_count.p, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(pack_centroids_split, dim3(ceil_div(nkb * 64, 256)), dim3(256), 0, st, dC, ws.off.p, k, s, nkb,
-                       reinterpret_cast<uint4 *>(ws.apack.p), ws.offp.p, ws.cmax2.p);
+                       reinterpret_cast<uint4 *>(ws.apack.p), ws.offp.p, ws.cmax2.p, ps.words);
     const long long npairs = ((long long)n + 63) / 64;
-    const size_t lds = (size_t)nkb * (3 * 64 * 16 + 64 * 4);
+    const size_t lds = (size_t)nkb * (na * 64 * 16 + 64 * 4);
     int grid = (int)std::min<long long>((npairs + 3) / 4, 256 * 8);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(assign_bf16, dim3(grid), dim3(256), lds, st, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n,
+    auto kern = ps.words == 3 ? assign_bf16<3, true> : ps.words == 4 ? assign_bf16<4, true> : ps.words == 5 ? assign_bf16<5, true>
+                                                                                                            : assign_bf16<3, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n,
                        npairs, reinterpret_cast<const uint4 *>(ws.apack.p), ws.offp.p, nkb, ws.cmax2.p, split_errk(s), d_assign,
                        ws.flag_rows.p, ws.flag_count.p, (float *)nullptr);
     HIP_CHECK(hipGetLastError());
@@ -884,14 +958,17 @@ double selftest_assign_band(int s, unsigned long long seed, float scale) {
   dX.upload(X.data(), X.size()); dC.upload(C.data(), C.size()); dOff.upload(off.data(), off.size());
   PackedSlice ps;
   pack_slice(dX.p, n, s, 0, s, k, ps, nullptr);
-  DevBuf<uint4> ap((size_t)3 * 64);
+  const int na = ps.words ? ps.words : 3;
+  DevBuf<uint4> ap((size_t)na * 64);
   DevBuf<float> offp(32);
   DevBuf<unsigned> cmax(1), fc(1);
   DevBuf<int> as(n), fr(n);
   HIP_CHECK(hipMemset(cmax.p, 0, 4)); HIP_CHECK(hipMemset(fc.p, 0, 4));
-  hipLaunchKernelGGL(pack_centroids_split, dim3(1), dim3(256), 0, 0, dC.p, dOff.p, k, s, 1, ap.p, offp.p, cmax.p);
-  const size_t lds = (size_t)(3 * 64 * 16 + 64 * 4);
-  hipLaunchKernelGGL(assign_bf16, dim3(1), dim3(256), lds, 0, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n, 1ll, ap.p,
+  hipLaunchKernelGGL(pack_centroids_split, dim3(1), dim3(256), 0, 0, dC.p, dOff.p, k, s, 1, ap.p, offp.p, cmax.p, ps.words);
+  const size_t lds = (size_t)(na * 64 * 16 + 64 * 4);
+  auto kern = ps.words == 3 ? assign_bf16<3, true> : ps.words == 4 ? assign_bf16<4, true> : ps.words == 5 ? assign_bf16<5, true>
+                                                                                                          : assign_bf16<3, false>;
+  hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, 0, reinterpret_cast<const uint4 *>(ps.xq.p), ps.xn.p, n, 1ll, ap.p,
                      offp.p, 1, cmax.p, split_errk(s), as.p, fr.p, fc.p, probe.p);
   HIP_CHECK(hipGetLastError());
   std::vector<float> got((size_t)n * k);
