@@ -604,7 +604,8 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
     struct Scan {
       float pin;       // running minimum key before the current block (both lanes of a row agree)
       float mband;     // smallest |key - running minimum| this LANE saw
-      int best;        // centroid of the running minimum (-1: none yet)
+      int best;        // where the running minimum sits: 2 * centroid block + (second half of the block?); -1: none yet
+                       // (the register inside the half is the key's low four bits: read off `pin` once, at the end)
     };
     Scan sx{FLT_MAX, INFINITY, -1}, sy{FLT_MAX, INFINITY, -1};
 
@@ -647,44 +648,26 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       const float m4 = fmin3(acc[12], acc[13], acc[14]);
       return fmin2(fmin3(m0, m1, m2), fmin3(m3, m4, acc[15]));
     };
-    // pass 2 over keys r, r + 1 of BOTH tiles, from running minima (px, py).  The two tiles' chains are written side by
-    // side: every instruction here is inline assembly, and the compiler puts a wait state between an inline-assembly
-    // instruction and a consumer that follows it directly (it has to assume a destination-select forwarding hazard) --
-    // one chain at a time cost 35 s_nop per block.
-    // Both differences of a tile (key - the running minimum before it) are ONE packed subtraction: the two keys are
-    // neighbouring accumulator registers, the two minima are kept as a register pair.
+    // pass 2 over keys r, r + 1 of BOTH tiles, from running minima (px, py); the two tiles' chains side by side.
+    // (Both differences of a tile as one v_pk_add_f32 -- the keys are neighbouring accumulator registers, the minima kept
+    // as a register pair -- was measured with the same compiler flags on one box: 18.5-18.8 ms per stage against 17.9-18.4
+    // with the two v_sub_f32.  The packed instruction saves an issue slot and costs more than it saves.)
     auto scan2 = [&](const f32x16 &cx, const f32x16 &cy, int r, float &px, float &py, float &mbx, float &mby) {
-#ifdef GULON_BF16_SCALAR_SUB
       const float kx0 = cx[r], kx1 = cx[r + 1], ky0 = cy[r], ky1 = cy[r + 1];
       const float qx0 = fmin2(px, kx0), qy0 = fmin2(py, ky0), qx1 = fmin2(qx0, kx1), qy1 = fmin2(qy0, ky1);
       const float dx0 = kx0 - px, dx1 = kx1 - qx0, dy0 = ky0 - py, dy1 = ky1 - qy0;
       asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mbx) : "v"(mbx), "v"(dx0), "v"(dx1));
       asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mby) : "v"(mby), "v"(dy0), "v"(dy1));
       px = qx1; py = qy1;
-#else
-      const f32x2 kx = {cx[r], cx[r + 1]}, ky = {cy[r], cy[r + 1]};
-      f32x2 ppx, ppy, ddx, ddy;
-      ppx.x = px; ppy.x = py;
-      ppx.y = fmin2(px, kx.x);
-      ppy.y = fmin2(py, ky.x);
-      const float qx = fmin2(ppx.y, kx.y);
-      const float qy = fmin2(ppy.y, ky.y);
-      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ddx) : "v"(kx), "v"(ppx));
-      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ddy) : "v"(ky), "v"(ppy));
-      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mbx) : "v"(mbx), "v"(ddx.x), "v"(ddx.y));
-      asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mby) : "v"(mby), "v"(ddy.x), "v"(ddy.y));
-      px = qx; py = qy;
-#endif
     };
     // after a block: the row's running minimum and where it sits.  lo / hi = the minima of the block's first and
     // second 16 centroids (both lanes of a row hold both after the exchange); branch-free
     auto close_block = [&](Scan &st, int kb, float lo, float hi) {
       const float blk = fmin2(lo, hi);
       // equal keys of the two halves (same distance bits, same register): the lower half's centroid comes first
-      const int cand = kb * 32 + (hi < lo ? 16 : 0) + (int)(__float_as_uint(blk) & 15u);
-      const bool better = blk < st.pin;                 // (a NaN never wins: such a row is flagged by its band)
-      st.best = better ? cand : st.best;
-      st.pin = better ? blk : st.pin;
+      const int where = hi < lo ? 2 * kb + 1 : 2 * kb;
+      st.best = blk < st.pin ? where : st.best;         // (a NaN never wins: such a row is flagged by its band)
+      st.pin = fmin2(st.pin, blk);
     };
     // One block: the scan of the accumulators (cx, cy) while the matrix instructions of the NEXT block -- the same row
     // tiles against centroid block kb + 1, or, at a pair's last block, the next pair's tiles against block 0 -- fill
@@ -792,7 +775,8 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       mband = (mine == mine && theirs == theirs) ? fminf(mine, theirs) : NAN;
     }
     const float pmin = upper ? sy.pin : sx.pin;
-    const int best = upper ? sy.best : sx.best;
+    const int where = upper ? sy.best : sx.best;
+    const int best = where < 0 ? -1 : 16 * where + (int)(__float_as_uint(pmin) & 15u);
     const long long row = pp * 64 + lane;
     const bool in_range = row < n;
     const bool my_amb = !(mband > e2);   // also true when mband is NaN
