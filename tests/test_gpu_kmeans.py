@@ -25,7 +25,9 @@ def _clustered(seed, n, d, kc=8):
 
 
 @pytest.mark.parametrize("n,d,frm,s,k,seed", [(3000, 16, 0, 4, 16, 0), (5000, 20, 7, 5, 25, 3), (70000, 8, 0, 8, 256, 1),
-                                              (4000, 40, 4, 33, 7, 2), (2000, 140, 3, 130, 5, 4), (500, 3, 1, 1, 3, 9)])
+                                              (4000, 40, 4, 33, 7, 2), (2000, 140, 3, 130, 5, 4), (500, 3, 1, 1, 3, 9),
+                                              # the matrix-core filter's operand layouts: 4 and 5 compact words, three pieces
+                                              (30000, 12, 1, 10, 256, 5), (30000, 16, 2, 13, 100, 6), (30000, 16, 1, 14, 256, 7)])
 def test_init_assign_update_bit_exact(oracle, g, n, d, frm, s, k, seed):
     X = _clustered(seed, n, d)
     dm = g.DeviceMatrix.from_host(X)
@@ -264,10 +266,11 @@ def test_more_than_10240_clusters(oracle, g, n, d, frm, s, k):
     assert np.array_equal(bits(trained.centroids), bits(Cc)) and len(reps) == len(oreps)
 
 
-@pytest.mark.parametrize("s", [1, 2, 5, 8, 9, 10, 16])
+@pytest.mark.parametrize("s", [1, 2, 5, 8, 9, 10, 11, 13, 14, 16])
 def test_bf16_split_filter_error_stays_inside_its_band(g, s):
-    """The bf16-split MFMA filter (three bf16 pieces per fp32 value, six products) may only differ from the reference's
-    fp32 chain (KMeans.scala:42-47) by its proven bound; the band test assumes twice that."""
+    """The bf16-split MFMA filter (three bf16 pieces per fp32 value, six products -- in 3 / 4 / 5 compact operand words for
+    s <= 8 / 10 / 13, one instruction per product beyond) may only differ from the reference's fp32 chain
+    (KMeans.scala:42-47) by its proven bound; the band test assumes twice that."""
     import ctypes as C
     worst = 0.0
     for seed, scale in ((1, 1.0), (2, 1e-3), (3, 300.0), (4, 1e6), (5, 1e-12)):
