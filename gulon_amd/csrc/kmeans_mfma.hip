@@ -547,6 +547,9 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
                                                    int *__restrict__ assign, int *__restrict__ flag_rows,
                                                    unsigned *__restrict__ flag_count, float *__restrict__ probe) {
   extern __shared__ float sm[];
+#ifdef GULON_BF16_CLOCKS   // experiment builds: shader cycles per 100 MHz tick over the life of workgroup 0
+  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
+#endif
   constexpr int NMF = COMPACT ? 2 * NA : 12;                       // matrix instructions per block and tile pair
   uint4 *sA = reinterpret_cast<uint4 *>(sm);                       // [nkb][NA][64]
   float *sOff = sm + (size_t)nkb * NA * 64 * 4;                     // 2 copies of nkb*32
@@ -790,6 +793,12 @@ __global__ __launch_bounds__(256) GULON_BF16_WAVES void assign_bf16(const uint4 
       if (flagged) flag_rows[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)row;
     }
   }
+#ifdef GULON_BF16_CLOCKS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long dc = clock64() - clk_c0, dw = wall_clock64() - clk_w0;
+    printf("[clocks] %llu shader cycles in %llu ticks of 10 ns: %.3f GHz\n", dc, dw, (double)dc / (double)dw / 10.0);
+  }
+#endif
 }
 
 // operand words per lane, tile and centroid block: 0 = three pieces (six matrix instructions), else the compact layout
