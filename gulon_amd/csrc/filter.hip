@@ -610,8 +610,11 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     w_first = cw[((size_t)(run_n < nruns ? block_of(p_n, r_n) : rb) * ng) * 64 + lane];
     run = run_n; e = e_n; e_run_end = end_n; mp_p = p_n; mp_r = r_n;
 
-    // acc[s][2*dd]   : 16-bit sums of queries 4dd (low half) and 4dd+2 (high half) of group s
-    // acc[s][2*dd+1] : queries 4dd+1 and 4dd+3
+    // acc[s][2*dd+1] : 16-bit sums of queries 4dd+1 (low half) and 4dd+3 (high half) of group s
+    // acc[s][2*dd]   : queries 4dd and 4dd+2 -- after the words.  While the words are walked it is the plain 32-bit sum W
+    //   of the byte-sum dwords: with S_i the sum of byte i, W = S0 + 2^8 S1 + 2^16 S2 + 2^24 S3 (mod 2^32) and the odd
+    //   accumulator is O = S1 + 2^16 S3 exactly, so W - 2^8 O = S0 + 2^16 S2 (mod 2^32, and that is below 2^32: every
+    //   S_i < 2^16) -- one subtraction per dword after the last word instead of a mask per dword and widening
     uint32_t acc[NQG][2 * DW];
 #pragma unroll
     for (int s = 0; s < NQG; s++)
@@ -671,7 +674,11 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
           }
 #pragma unroll
           for (int dd = 0; dd < DW; dd++) {
+#ifdef GULON_FILTER_MASKED_EVEN
             acc[s][2 * dd] += xs[dd] & 0x00FF00FFu;
+#else
+            acc[s][2 * dd] += xs[dd];                                                // (unmasked: see `acc`)
+#endif
             acc[s][2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
           }
         }
@@ -704,7 +711,11 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
           }
 #pragma unroll
           for (int dd = 0; dd < DW; dd++) {
+#ifdef GULON_FILTER_MASKED_EVEN
             acc[s][2 * dd] += xs[dd] & 0x00FF00FFu;
+#else
+            acc[s][2 * dd] += xs[dd];                                                // (unmasked: see `acc`)
+#endif
             acc[s][2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
           }
         }
@@ -724,6 +735,12 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(
     else
       for (int g = 0; g < ng; g++) w = word(g, std::false_type{}, w);
 
+#ifndef GULON_FILTER_MASKED_EVEN
+#pragma unroll
+    for (int s = 0; s < NQG; s++)
+#pragma unroll
+      for (int dd = 0; dd < DW; dd++) acc[s][2 * dd] -= acc[s][2 * dd + 1] << 8;
+#endif
     // conflict-ordered copy: which row a lane holds is only looked up (one byte) when a lane has something to report
     constexpr bool PERM = NG1 == 2;
     int row = rb * 64 + lane;
