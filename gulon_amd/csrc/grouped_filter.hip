@@ -468,7 +468,7 @@ __global__ __launch_bounds__(GF_THREADS) void gf_filter(const uint8_t *__restric
         }
 #pragma unroll
         for (int dd = 0; dd < 4; dd++) {
-          acc[2 * dd] += xs[dd] & 0x00FF00FFu;
+          acc[2 * dd] += xs[dd];                                                   // (unmasked: corrected below)
           acc[2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
         }
       }
@@ -477,10 +477,15 @@ __global__ __launch_bounds__(GF_THREADS) void gf_filter(const uint8_t *__restric
         const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
         for (int dd = 0; dd < 4; dd++) {
-          acc[2 * dd] += ys[dd] & 0x00FF00FFu;
+          acc[2 * dd] += ys[dd];
           acc[2 * dd + 1] += __builtin_amdgcn_perm(0u, ys[dd], 0x0C030C01u);
         }
       }
+      // filter.hip's running sum: acc[2 dd] holds W = S0 + 2^8 S1 + 2^16 S2 + 2^24 S3 (mod 2^32; S_i = the sum of byte i
+      // over the 17 tables, < 2^13) and acc[2 dd + 1] = S1 + 2^16 S3 exactly, so W - 2^8 acc[2 dd + 1] = S0 + 2^16 S2 -- one
+      // subtraction per dword here instead of a mask per table
+#pragma unroll
+      for (int dd = 0; dd < 4; dd++) acc[2 * dd] -= acc[2 * dd + 1] << 8;
       uint32_t left[8], any = 0;
 #pragma unroll
       for (int x = 0; x < 8; x++) {
