@@ -272,6 +272,11 @@ __global__ __launch_bounds__(256) void gq_sorted_groups(const float *__restrict_
 // by a 4-pass radix select on the float bits (distances are >= +0: unsigned order), everything at or
 // below it is compacted (limit + ties entries) and only that is sorted by (distance, id).
 // ok[q] = 0 if more than `cap` entries tie at the threshold (the caller then sorts everything).
+// KR > 0: the query's g <= 256 KR keys are read ONCE and kept in registers through the four counting passes and the
+// compaction (the kernel is one workgroup's latency -- all B of them are resident at once: five trips through the
+// 40 KB of a query's distances and a 256-step serial walk over the bins per pass were most of its 134 us); KR = 0: any g,
+// from memory.
+template <int KR>
 __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict__ cdist, int g, int limit, int cap,
                                                         int *__restrict__ nn, int stride,
                                                         int *__restrict__ nn_cnt, int *__restrict__ ok,
@@ -287,15 +292,35 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
   auto keyof = [&](int c) { const float v = dq[c]; return v != v ? 0x7F800000u : __float_as_uint(v); };   // NaN orders last
   const int want = min(limit, g);
   if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)want; s_count = 0; s_lit = 0; }
+  constexpr int KRN = KR > 0 ? KR : 1;
+  unsigned kreg[KRN];                                      // key of centroid tid + 256 r (0xFFFFFFFF: none)
+  bool any_nan = false;
+  if (KR > 0) {
+#pragma unroll
+    for (int r = 0; r < KRN; r++) {
+      const int c = tid + 256 * r;
+      const float v = c < g ? dq[c] : 0.f;
+      any_nan = any_nan || v != v;
+      kreg[r] = c < g ? (v != v ? 0x7F800000u : __float_as_uint(v)) : 0xFFFFFFFFu;
+    }
+  }
   __syncthreads();
   unsigned mask = 0u;
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int e = tid; e < 256 * 8; e += 256) hsub[e] = 0u;
     __syncthreads();
     const unsigned prefix = s_prefix;
-    for (int c = tid; c < g; c += 256) {
-      const unsigned key = keyof(c);
-      if ((key & mask) == prefix) atomicAdd(&hsub[((key >> shift) & 255u) * 8 + (tid & 7)], 1u);
+    if (KR > 0) {
+#pragma unroll
+      for (int r = 0; r < KRN; r++) {
+        const unsigned key = kreg[r];
+        if (key != 0xFFFFFFFFu && (key & mask) == prefix) atomicAdd(&hsub[((key >> shift) & 255u) * 8 + (tid & 7)], 1u);
+      }
+    } else {
+      for (int c = tid; c < g; c += 256) {
+        const unsigned key = keyof(c);
+        if ((key & mask) == prefix) atomicAdd(&hsub[((key >> shift) & 255u) * 8 + (tid & 7)], 1u);
+      }
     }
     __syncthreads();
     {
@@ -305,26 +330,54 @@ __global__ __launch_bounds__(256) void gq_select_groups(const float *__restrict_
       hist[tid] = h;
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = s_remaining, cum = 0u;
-      int b = 0;
-      for (; b < 255; b++) {
-        if (cum + hist[b] >= rem) break;
-        cum += hist[b];
+    if (tid < 64) {
+      // the bin in which the running count reaches `remaining`: four bins per lane, a prefix sum over the lanes
+      const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o);
+        if (tid >= o) incl += up;
       }
-      s_remaining = rem - cum;
-      s_prefix = prefix | ((unsigned)b << shift);
+      const unsigned rem = s_remaining;
+      const unsigned long long reach = __ballot(incl >= rem);
+      // (the serial walk stopped at bin 255 at the latest: a total below `remaining` cannot happen -- every pass keeps
+      // at least `remaining` keys -- but the last lane takes it then, as the walk did)
+      const int first = reach ? __ffsll((long long)reach) - 1 : 63;
+      if (tid == first) {
+        unsigned cum = incl - mine;
+        int b = 4 * tid;
+        if (cum + h0 >= rem) { }
+        else if (cum + h0 + h1 >= rem) { cum += h0; b += 1; }
+        else if (cum + h0 + h1 + h2 >= rem) { cum += h0 + h1; b += 2; }
+        else { cum += h0 + h1 + h2; b += 3; }
+        s_remaining = rem - cum;
+        s_prefix = prefix | ((unsigned)b << shift);
+      }
     }
     mask |= 255u << shift;
     __syncthreads();
   }
   const unsigned thr = s_prefix;                           // key of the want-th smallest distance
-  for (int c = tid; c < g; c += 256) {
-    const unsigned key = keyof(c);
-    if (dq[c] != dq[c]) s_lit = 2;                         // NaN distance: literal heap (gq_literal_groups)
-    if (key <= thr) {
-      const int p = atomicAdd(&s_count, 1);
-      if (p < cap) { sv[p] = __uint_as_float(key); si[p] = c; }
+  if (KR > 0) {
+    if (any_nan) s_lit = 2;                                // NaN distance: literal heap (gq_literal_groups)
+#pragma unroll
+    for (int r = 0; r < KRN; r++) {
+      const unsigned key = kreg[r];
+      if (key != 0xFFFFFFFFu && key <= thr) {
+        const int p = atomicAdd(&s_count, 1);
+        if (p < cap) { sv[p] = __uint_as_float(key); si[p] = tid + 256 * r; }
+      }
+    }
+  } else {
+    for (int c = tid; c < g; c += 256) {
+      const unsigned key = keyof(c);
+      if (dq[c] != dq[c]) s_lit = 2;                       // NaN distance: literal heap (gq_literal_groups)
+      if (key <= thr) {
+        const int p = atomicAdd(&s_count, 1);
+        if (p < cap) { sv[p] = __uint_as_float(key); si[p] = c; }
+      }
     }
   }
   __syncthreads();
@@ -1235,9 +1288,9 @@ void run_grouped_query(gulon_grouped_index *gx, const float *dQ, int B, int K, i
       while (cap < limit + 128) cap <<= 1;
       gx->sel_ok.ensure((size_t)B);
       const size_t sel_lds = (size_t)cap * 8;
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gq_select_groups),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-      hipLaunchKernelGGL(gq_select_groups, dim3(B), dim3(256), sel_lds, st, gx->cdist.p, g, limit, cap, gx->nn.p,
+      auto kern = g <= 256 * 8 ? gq_select_groups<8> : g <= 256 * 40 ? gq_select_groups<40> : gq_select_groups<0>;
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+      hipLaunchKernelGGL(kern, dim3(B), dim3(256), sel_lds, st, gx->cdist.p, g, limit, cap, gx->nn.p,
                          nn_stride, gx->nn_cnt.p, gx->sel_ok.p, gx->lit_flag.p);
       done = gx->sel_ok.p;
     }
