@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void gf_quant(float *__restrict__ P /* out: th
   float *qv = gq_sm, *tab = gq_sm + d, *vals = tab + m_pad * 256;
   __shared__ float s_lo[16], s_mb[4], s_sbase[GF_SAMPLE_GROUPS];
   __shared__ int s_bad, s_sc[GF_SAMPLE_GROUPS], s_sr0[GF_SAMPLE_GROUPS], s_soff[GF_SAMPLE_GROUPS + 1], s_ns;
+  __shared__ unsigned s_hist[256], s_prefix, s_remaining;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *Pq = P + (size_t)q * m_pad * 256;
   for (int e = tid; e < d; e += 256) qv[e] = Q[(size_t)q * d + e];
@@ -229,38 +230,84 @@ __global__ __launch_bounds__(256) void gf_quant(float *__restrict__ P /* out: th
     if (lane == 0) s_sbase[t] = qq - 2.0f * qg;
   }
   __syncthreads();
-  int n2 = 64;
-  while (n2 < total) n2 <<= 1;
-  for (int i = tid; i < n2; i += 256) {        // D~ of the sampled rows (gq_approx_scan's sum, term by term)
-    float acc = INFINITY;
+  // D~ of the sampled rows (gq_approx_scan's sum, term by term), as order-preserving keys in registers: up to
+  // GF_SAMPLE_ROWS / 256 = 8 per thread
+  constexpr int SR = GF_SAMPLE_ROWS / 256;
+  unsigned skey[SR];
+#pragma unroll
+  for (int r = 0; r < SR; r++) {
+    const int i = tid + 256 * r;
+    skey[r] = 0xFFFFFFFFu;                     // (no row; a real key is never this: NaN values become +inf below)
     if (i < total) {
       int t = 0;
       while (t + 1 < ns && i >= s_soff[t + 1]) t++;
       const int row = s_sr0[t] + (i - s_soff[t]);
       const uint4 w = gf_row_words<VEC>(codes, ng, row);
-      acc = s_sbase[t] + xnorm[row];
+      float acc = s_sbase[t] + xnorm[row];
       for (int j = 0; j < m_pad; j++) {
         const uint32_t x = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
         acc += tab[j * 256 + ((x >> (8 * (j & 3))) & 0xFFu)];
       }
       bad = bad || acc != acc;
       if (acc != acc) acc = INFINITY;
+      const unsigned u = __float_as_uint(acc);
+      skey[r] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // unsigned order = float order
     }
-    vals[i] = acc;
   }
-  __syncthreads();
-  for (int kk = 2; kk <= n2; kk <<= 1)         // ascending bitonic sort
-    for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
-      for (int i = tid; i < n2; i += 256) {
-        const int l = i ^ jj;
-        if (l > i) {
-          const float a = vals[i], b = vals[l];
-          if ((a > b) == ((i & kk) == 0)) { vals[i] = b; vals[l] = a; }
-        }
+  // the 64th smallest of them (+inf with fewer than 64 rows: keep every row): a four-pass radix select over the keys in
+  // registers -- 16 barriers where the bitonic sort of up to 2048 values in LDS took 66 (gq_select_groups' scheme: eight
+  // sub-counters per bin, the bins walked by a prefix sum over one wavefront)
+  float tq = INFINITY;
+  if (total >= GF_LIST) {                      // (uniform over the workgroup)
+    unsigned *hsub = reinterpret_cast<unsigned *>(vals);          // [256][8]: GF_SAMPLE_ROWS words
+    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)GF_LIST; }
+    unsigned mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int e = tid; e < 256 * 8; e += 256) hsub[e] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+#pragma unroll
+      for (int r = 0; r < SR; r++) {
+        const unsigned key = skey[r];
+        if (key != 0xFFFFFFFFu && (key & mask) == prefix) atomicAdd(&hsub[((key >> shift) & 255u) * 8 + (tid & 7)], 1u);
       }
       __syncthreads();
+      {
+        unsigned h = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) h += hsub[tid * 8 + x];
+        s_hist[tid] = h;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const unsigned h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+        const unsigned mine = h0 + h1 + h2 + h3;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned up = __shfl_up(incl, o);
+          if (tid >= o) incl += up;
+        }
+        const unsigned rem = s_remaining;
+        const unsigned long long reach = __ballot(incl >= rem);
+        const int first = reach ? __ffsll((long long)reach) - 1 : 63;
+        if (tid == first) {
+          unsigned cum = incl - mine;
+          int bin = 4 * tid;
+          if (cum + h0 >= rem) { }
+          else if (cum + h0 + h1 >= rem) { cum += h0; bin += 1; }
+          else if (cum + h0 + h1 + h2 >= rem) { cum += h0 + h1; bin += 2; }
+          else { cum += h0 + h1 + h2; bin += 3; }
+          s_remaining = rem - cum;
+          s_prefix = prefix | ((unsigned)bin << shift);
+        }
+      }
+      mask |= 255u << shift;
+      __syncthreads();
     }
-  const float tq = total >= GF_LIST ? vals[GF_LIST - 1] : INFINITY;   // the 64th smallest D~ of real rows (+inf: keep every row)
+    const unsigned t = s_prefix;
+    tq = __uint_as_float((t & 0x80000000u) ? (t & 0x7FFFFFFFu) : ~t);
+  }
   // a lower bound of |q|^2 - 2 q.g over the searched groups, from the centroid distances the group selection already
   // has: |q - g|^2 - |g|^2, less what the two roundings can differ by (it only sizes the step; the budgets themselves
   // use gq_approx_scan's own base)
