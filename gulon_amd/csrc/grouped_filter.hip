@@ -573,67 +573,136 @@ __global__ __launch_bounds__(64 * GF_WAVES) void gf_survivors(const uint8_t *__r
                                                               const int *__restrict__ qcnt, const uint2 *__restrict__ queue,
                                                               float *__restrict__ lv, int *__restrict__ li,
                                                               int *__restrict__ nanflag) {
-  extern __shared__ float tab[];               // m_pad * 256 table entries
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
-  for (int e = tid; e < m_pad * 256; e += 64 * GF_WAVES) tab[e] = P[(size_t)q * m_pad * 256 + e];
+  // The GF_LIST smallest (D~, row) of the query's survivors, ascending.  Every survivor is scored into a register (an
+  // order-preserving key and the row: up to GF_CAP / 1024 = 16 per thread, usually one); the GF_LIST-th smallest key is
+  // found by a four-pass radix select over those registers (gf_quant's, gq_select_groups' scheme), the entries at or
+  // below it are compacted into LDS and each of them finds its place by counting the entries below it.  (Sixteen wave
+  // lists -- serial insertions -- and a bitonic sort of their 1024 entries, 55 barriers of a 1024-thread workgroup, before.)
+  extern __shared__ float tab[];               // m_pad * 256 table entries; afterwards the select's counters and the compacted entries
+  __shared__ unsigned s_hist[256], s_prefix, s_remaining;
+  __shared__ int s_nan, s_cnt;
+  constexpr int NT = 64 * GF_WAVES, PER = GF_CAP / NT;
+  const int tid = threadIdx.x, lane = tid & 63, q = blockIdx.x;
+  for (int e = tid; e < m_pad * 256; e += NT) tab[e] = P[(size_t)q * m_pad * 256 + e];
+  if (tid == 0) { s_nan = 0; s_cnt = 0; s_prefix = 0u; }
   __syncthreads();
   const int total = qcnt[q], n_e = min(total, GF_CAP);
-  WaveList wl;
-  wl.init();
-  int cnt = 0, saw_nan = total > GF_CAP ? 1 : 0;               // an overflowing queue has lost rows: the literal kernels
-  for (int e0 = wave * 64; e0 < n_e; e0 += 64 * GF_WAVES) {
-    const bool valid = e0 + lane < n_e;
-    const uint2 ent = valid ? queue[(size_t)q * GF_CAP + e0 + lane] : uint2{0u, 0u};
-    const int row = (int)ent.x;
-    const uint4 w = gf_row_words<VEC>(codes, ng, row);
-    float acc = __uint_as_float(ent.y) + (valid ? xnorm[row] : 0.f);
-    if constexpr (VEC == 16) {
+  const int want = min(GF_LIST, n_e);
+  unsigned key[PER];
+  int rowv[PER];
+  bool nanv = false;
 #pragma unroll
-      for (int b = 0; b < 16; b++) acc += tab[b * 256 + code_byte<16>(w, b)];
-    } else {
-      for (int gi = 0; gi < ng; gi++) {        // quantizers 0 .. m_pad - 1 in order, as gq_approx_scan<4> adds them
-        const uint32_t x = gi == 0 ? w.x : gi == 1 ? w.y : gi == 2 ? w.z : w.w;
+  for (int h = 0; h < PER; h++) {
+    key[h] = 0xFFFFFFFFu;                      // (no entry; a real key is never this: NaN values become +inf)
+    rowv[h] = INT_MAX;
+    if (h * NT < n_e) {                        // (uniform)
+      const int e = tid + h * NT;
+      if (e < n_e) {
+        const uint2 ent = queue[(size_t)q * GF_CAP + e];
+        const int row = (int)ent.x;
+        const uint4 w = gf_row_words<VEC>(codes, ng, row);
+        float acc = __uint_as_float(ent.y) + xnorm[row];
+        if constexpr (VEC == 16) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc += tab[(gi * 4 + b) * 256 + ((x >> (8 * b)) & 0xFFu)];
-      }
-    }
-    if (__ballot(valid && acc != acc) != 0ull) saw_nan = 1;
-    unsigned long long mk = __ballot(valid && (cnt < GF_LIST || wl.accepts(acc, row)));
-    while (mk) {
-      const int l = __ffsll((long long)mk) - 1;
-      mk &= mk - 1;
-      const float x = readlane_f(acc, l);
-      const int r = __builtin_amdgcn_readlane(row, l);
-      if (cnt < GF_LIST || wl.accepts(x, r)) {
-        wl.insert(x, r, GF_LIST, lane);
-        if (cnt < GF_LIST) cnt++;
+          for (int b = 0; b < 16; b++) acc += tab[b * 256 + code_byte<16>(w, b)];
+        } else {
+          for (int gi = 0; gi < ng; gi++) {    // quantizers 0 .. m_pad - 1 in order, as gq_approx_scan<4> adds them
+            const uint32_t x = gi == 0 ? w.x : gi == 1 ? w.y : gi == 2 ? w.z : w.w;
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc += tab[(gi * 4 + b) * 256 + ((x >> (8 * b)) & 0xFFu)];
+          }
+        }
+        if (acc != acc) { nanv = true; acc = INFINITY; }
+        const unsigned u = __float_as_uint(acc);
+        key[h] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // unsigned order = float order
+        rowv[h] = row;
       }
     }
   }
-  // the sixteen waves' lists -> the query's GF_LIST smallest, ascending by (value, row): what merge_lists makes of
-  // gq_approx_scan's lists, here by one bitonic sort of the 1024 entries in LDS (the table is no longer needed)
-  __shared__ int s_nan;
-  if (tid == 0) s_nan = 0;
-  __syncthreads();
-  float *sv = tab;
-  int *si = reinterpret_cast<int *>(tab + 64 * GF_WAVES);
-  sv[tid] = wl.v;
-  si[tid] = wl.i;
-  if (lane == 0 && saw_nan) atomicOr(&s_nan, 1);
-  __syncthreads();
-  for (int kk = 2; kk <= 64 * GF_WAVES; kk <<= 1)
-    for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
-      const int l = tid ^ jj;
-      if (l > tid) {
-        const float a = sv[tid], b = sv[l];
-        const int ai = si[tid], bi = si[l];
-        const bool gt = a > b || (a == b && ai > bi);
-        if (gt == ((tid & kk) == 0)) { sv[tid] = b; sv[l] = a; si[tid] = bi; si[l] = ai; }
+  if (tid == 0) s_remaining = (unsigned)max(want, 1);
+  __syncthreads();                                               // (the tables have been read)
+  unsigned *hsub = reinterpret_cast<unsigned *>(tab);            // [256][8]
+  unsigned *ck = hsub + 256 * 8;                                 // [GF_PLACED] compacted keys
+  int *ci = reinterpret_cast<int *>(ck + GF_PLACED);             // [GF_PLACED] ... and rows
+  unsigned mask = 0u;
+  if (want > 0) {                                                // (uniform)
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int e = tid; e < 256 * 8; e += NT) hsub[e] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+#pragma unroll
+      for (int h = 0; h < PER; h++)
+        if (h * NT < n_e) {
+          const unsigned k = key[h];
+          if (k != 0xFFFFFFFFu && (k & mask) == prefix) atomicAdd(&hsub[((k >> shift) & 255u) * 8 + (tid & 7)], 1u);
+        }
+      __syncthreads();
+      if (tid < 256) {
+        unsigned hh = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) hh += hsub[tid * 8 + x];
+        s_hist[tid] = hh;
       }
       __syncthreads();
+      if (tid < 64) {
+        const unsigned h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+        const unsigned mine = h0 + h1 + h2 + h3;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned up = __shfl_up(incl, o);
+          if (tid >= o) incl += up;
+        }
+        const unsigned rem = s_remaining;
+        const unsigned long long reach = __ballot(incl >= rem);
+        const int first = reach ? __ffsll((long long)reach) - 1 : 63;
+        if (tid == first) {
+          unsigned cum = incl - mine;
+          int bin = 4 * tid;
+          if (cum + h0 >= rem) { }
+          else if (cum + h0 + h1 >= rem) { cum += h0; bin += 1; }
+          else if (cum + h0 + h1 + h2 >= rem) { cum += h0 + h1; bin += 2; }
+          else { cum += h0 + h1 + h2; bin += 3; }
+          s_remaining = rem - cum;
+          s_prefix = prefix | ((unsigned)bin << shift);
+        }
+      }
+      mask |= 255u << shift;
+      __syncthreads();
     }
-  if (tid < GF_LIST) { lv[(size_t)q * GF_LIST + tid] = sv[tid]; li[(size_t)q * GF_LIST + tid] = si[tid]; }
-  if (tid < GF_WAVES) nanflag[q * GF_WAVES + tid] = tid == 0 ? s_nan : 0;
+    const unsigned thr = s_prefix;                               // key of the want-th smallest value
+#pragma unroll
+    for (int h = 0; h < PER; h++)
+      if (h * NT < n_e) {
+        const unsigned k = key[h];
+        if (k != 0xFFFFFFFFu && k <= thr) {
+          const int p = atomicAdd(&s_cnt, 1);
+          if (p < GF_PLACED) { ck[p] = k; ci[p] = rowv[h]; }
+        }
+      }
+  }
+  if (__ballot(nanv) != 0ull && lane == 0) atomicOr(&s_nan, 1);
+  __syncthreads();
+  const int c = s_cnt;                                           // >= want: the want smallest and whatever ties with the last
+  if (c <= GF_PLACED) {
+    for (int t = tid; t < c; t += NT) {
+      const unsigned k = ck[t];
+      const int r = ci[t];
+      int place = 0;
+      for (int j = 0; j < c; j++) {
+        const unsigned kj = ck[j];
+        const int rj = ci[j];
+        place += (kj < k || (kj == k && rj < r)) ? 1 : 0;
+      }
+      if (place < GF_LIST) {
+        lv[(size_t)q * GF_LIST + place] = __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+        li[(size_t)q * GF_LIST + place] = r;
+      }
+    }
+  }
+  if ((tid >= want || c > GF_PLACED) && tid < GF_LIST) { lv[(size_t)q * GF_LIST + tid] = INFINITY; li[(size_t)q * GF_LIST + tid] = INT_MAX; }
+  // an overflowing queue has lost rows, a NaN value or more ties at the cut than the placing holds: the literal kernels
+  if (tid < GF_WAVES) nanflag[q * GF_WAVES + tid] = tid == 0 ? ((s_nan != 0 || total > GF_CAP || c > GF_PLACED) ? 1 : 0) : 0;
 }
 
 }  // namespace
@@ -725,7 +794,7 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
   }
   {
     auto kern = vec == 16 ? gf_survivors<16> : gf_survivors<4>;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GF_WAVES), sizeof(float) * std::max((size_t)m_pad * 256, (size_t)2 * 64 * GF_WAVES), st,
+    hipLaunchKernelGGL(kern, dim3(B), dim3(64 * GF_WAVES), sizeof(float) * std::max((size_t)m_pad * 256, (size_t)256 * 8 + 2 * GF_PLACED), st,
                        codes, ng, m_pad, P, xnorm,
                        gf.qcnt.p, gf.queue.p, amv, ami, anan);
   }
