@@ -108,40 +108,46 @@ __global__ void gf_gnorm(const float *__restrict__ gcent, int g, int d, float *_
 }
 
 // ---- per batch: for every group the queries that search it -------------------------------------------
-// toff: first tile (GF_QT pairs) of every group; meta[0] = tiles, meta[1] = pairs
-__global__ __launch_bounds__(1024) void gf_scan(const int *__restrict__ gcnt, int g, int *__restrict__ toff, int *__restrict__ meta) {
-  __shared__ int sa[1024], sb[1024];
-  const int tid = threadIdx.x, per = (g + 1023) / 1024;
-  const int lo = min(g, tid * per), hi = min(g, lo + per);
-  int a = 0, b = 0;
-  for (int c = lo; c < hi; c++) { a += gcnt[c]; b += (gcnt[c] + GF_QT - 1) / GF_QT; }
-  sa[tid] = a; sb[tid] = b;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
-    __syncthreads();
-    sa[tid] += va; sb[tid] += vb;
-    __syncthreads();
-  }
-  int eb = sb[tid] - b;
-  for (int c = lo; c < hi; c++) {
-    toff[c] = eb;
-    eb += (gcnt[c] + GF_QT - 1) / GF_QT;
-  }
-  if (tid == 1023) { toff[g] = sb[1023]; meta[0] = sb[1023]; meta[1] = sa[1023]; }
-}
-
 // (Leaving out the pairs whose budget is negative even for the group's best row -- threshold - table minima -
 // (|q - g|^2 - |g|^2 + the group's smallest row norm) < 0 -- was tried: under 1 % of the pairs at 10 M rows /
 // LimitGroups(500), for two scattered loads per pair.  The lists themselves: every group has room for all B queries
 // (pairs[c][B]), so a query is appended where it is counted, in gf_quant -- no offsets, no second pass over the pairs.)
 
 // everything a tile's workgroup needs to start, in one record (one scalar round trip instead of four dependent ones)
-__global__ void gf_tiles(const int *__restrict__ gcnt, const int *__restrict__ toff, int g, int B, const int *__restrict__ bounds,
-                         const float *__restrict__ xnlo, const int *__restrict__ pairs, GfTile *__restrict__ tiles) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// A group's first tile = the tiles of the groups before it: every workgroup adds those up itself (at most g counters,
+// 40 KB from L2 -- a scan kernel of its own in front of this one cost a launch for 10 us of work); the last workgroup
+// also leaves the totals (meta[0] = tiles, meta[1] = pairs).
+__global__ __launch_bounds__(256) void gf_tiles(const int *__restrict__ gcnt, int g, int B, const int *__restrict__ bounds,
+                                                const float *__restrict__ xnlo, const int *__restrict__ pairs,
+                                                GfTile *__restrict__ tiles, int *__restrict__ meta) {
+  __shared__ int s_t[8], s_p[4];
+  const int tid = threadIdx.x, c = blockIdx.x * 256 + tid;
+  const int c0 = blockIdx.x * 256;
+  int before = 0, pbefore = 0;                 // tiles (and pairs) of the groups in front of this workgroup's
+  for (int e = tid; e < c0; e += 256) { const int n = gcnt[e]; before += (n + GF_QT - 1) / GF_QT; pbefore += n; }
+  const int cnt = c < g ? gcnt[c] : 0;
+  const int mine = (cnt + GF_QT - 1) / GF_QT;
+  // inclusive prefix of `mine` over the workgroup + the total of `before`
+  int incl = mine, bsum = before, psum = cnt + pbefore;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += up;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { bsum += __shfl_xor(bsum, o); psum += __shfl_xor(psum, o); }
+  if ((tid & 63) == 63) s_t[tid >> 6] = incl;
+  if ((tid & 63) == 0) { s_t[4 + (tid >> 6)] = bsum; s_p[tid >> 6] = psum; }
+  __syncthreads();
+  int base = s_t[4] + s_t[5] + s_t[6] + s_t[7];
+  for (int w = 0; w < (tid >> 6); w++) base += s_t[w];
+  const int t1 = base + incl, t0 = t1 - mine;
+  if (blockIdx.x == gridDim.x - 1 && tid == 255) {
+    // (pairs: counted only for the debugging aid's report)
+    meta[0] = t1;
+    meta[1] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+  }
   if (c >= g) return;
-  const int t0 = toff[c], t1 = toff[c + 1], cnt = gcnt[c];
   for (int t = t0; t < t1; t++) {
     const int first = (t - t0) * GF_QT;
     GfTile T;
@@ -751,7 +757,7 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
   const size_t pairs_max = (size_t)B * nn_stride;
   const size_t tiles_max = pairs_max / GF_QT + (size_t)g + 1;
   GULON_UNSUPPORTED(tiles_max >= (1ull << 31), "too many (query, group) pairs");
-  gf.gcnt.ensure((size_t)g + 1); gf.toff.ensure((size_t)g + 1);
+  gf.gcnt.ensure((size_t)g + 1);
   gf.pairs.ensure((size_t)g * B); gf.tiles.ensure(tiles_max); gf.meta.ensure(4); gf.qcnt.ensure((size_t)B);
   gf.qb.ensure((size_t)B * GF_NT * 256); gf.qs.ensure((size_t)B * 4); gf.queue.ensure((size_t)B * GF_CAP);
   HIP_CHECK(hipMemsetAsync(gf.gcnt.p, 0, sizeof(int) * ((size_t)g + 1), st));
@@ -763,9 +769,8 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
     hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, pq_cents, from, sdim, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
                        nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.gcnt.p, gf.pairs.p, B, gf.qb.p, gf.qs.p);
   }
-  hipLaunchKernelGGL(gf_scan, dim3(1), dim3(1024), 0, st, gf.gcnt.p, g, gf.toff.p, gf.meta.p);
-  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, 256)), dim3(256), 0, st, gf.gcnt.p, gf.toff.p, g, B, bounds, gf.xnlo.p, gf.pairs.p,
-                     gf.tiles.p);
+  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, 256)), dim3(256), 0, st, gf.gcnt.p, g, B, bounds, gf.xnlo.p, gf.pairs.p, gf.tiles.p,
+                     gf.meta.p);
   HIP_CHECK(hipGetLastError());
   const size_t lds_f = sizeof(uint4) * GF_NT * 256;
   static const bool attr = [&] {

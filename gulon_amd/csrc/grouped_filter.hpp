@@ -29,7 +29,7 @@ struct GroupFilter {
   float gnmax = 0.f;
   bool built = false;
   // scratch
-  DevBuf<int> gcnt, toff, pairs /* [g][B]: every group's queries */, meta, qcnt;
+  DevBuf<int> gcnt, pairs /* [g][B]: every group's queries */, meta, qcnt;
   DevBuf<GfTile> tiles;
   DevBuf<uint8_t> qb;           // [B][17][256] levels: 16 quantizers and the row-norm level
   DevBuf<float> qs;             // [B][4]: budget at base 0, 1 / step, spare, spare
