@@ -195,7 +195,7 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
 #pragma unroll
     for (int x = 0; x < 2 * DW; x++) acc[x] = 0;
     if (SLICED && jlo > 0) {   // the earlier slices' sums: bytes q0 | q1 << 8 | q2 << 16 | q3 << 24
-      acc[0] = pw & 0x00FF00FFu;
+      acc[0] = pw;                                  // (unmasked, like every term of acc[2 dd]: corrected after the groups)
       acc[1] = (pw >> 8) & 0x00FF00FFu;
     }
     auto group = [&](const int j, const int cnt4, auto from_regs) {   // quantizers j .. j + cnt4 - 1 (cnt4 <= 4)
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
       }
 #pragma unroll
       for (int dd = 0; dd < DW; dd++) {
-        acc[2 * dd] += xs[dd] & 0x00FF00FFu;
-        acc[2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3
+        acc[2 * dd] += xs[dd];                                               // filter.hip's running sum: W = S0 + 2^8 S1 + 2^16 S2 + 2^24 S3
+        acc[2 * dd + 1] += __builtin_amdgcn_perm(0u, xs[dd], 0x0C030C01u);   // bytes 1 and 3: O = S1 + 2^16 S3
       }
     };
     if (MQ > 0) {
@@ -229,6 +229,8 @@ __global__ __launch_bounds__(WF_THREADS) void wf_filter(const uint16_t *__restri
       for (; j + 4 <= jhi; j += 4) group(j, 4, std::false_type{});
       if (j < jhi) group(j, jhi - j, std::false_type{});
     }
+#pragma unroll
+    for (int dd = 0; dd < DW; dd++) acc[2 * dd] -= acc[2 * dd + 1] << 8;     // W - 2^8 O = S0 + 2^16 S2
     if (SLICED && jhi < m) {   // not the last slice: park the sums, one byte per query, saturated
       uint32_t a, b;
       asm("v_pk_min_u16 %0, %1, %2" : "=v"(a) : "v"(acc[0]), "v"(0x00FF00FFu));
