@@ -144,6 +144,7 @@ def test_bad_arguments(g):
     (120000, 32, 400, 16, 256, 120, 0, False),     # the regime it is built for: many groups, m = 16
     (60000, 24, 300, 8, 64, 90, 3000, False),      # duplicated rows: equal D~ at the cut, ties in the re-ranking
     (60000, 16, 250, 4, 16, 250, 0, True),         # every group searched; a NaN query and a far-away query
+    (66000, 8, 11000, 4, 16, 100, 0, False),       # more groups than the group selection keeps keys in registers for
 ])
 def test_by_group_filter_equals_reference(oracle, g, monkeypatch, capfd, n, d, groups, m, k, limit, dup, bad_query):
     """GroupedIndex.query (Index.scala:265-299) through the by-group pre-selection with 8-bit bound tables
@@ -159,6 +160,32 @@ def test_by_group_filter_equals_reference(oracle, g, monkeypatch, capfd, n, d, g
     if bad_query:
         Q[3, 1] = np.nan
         Q[4] *= np.float32(1e4)
+    oi, od, oc = index.batch_query_raw(K, Q)
+    assert "by-group filter" in capfd.readouterr().err
+    ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, 0, limit)
+    assert np.array_equal(oc, ec)
+    for q in range(B):
+        assert oi[q, :oc[q]].tolist() == ei[q, :ec[q]].tolist(), q
+        assert np.array_equal(bits(od[q, :oc[q]]), bits(ed[q, :ec[q]])), q
+    index.close()
+
+
+def test_by_group_filter_with_hundreds_of_ties_at_the_cut(oracle, g, monkeypatch, capfd):
+    """700 copies of one row: for a query at that row they all share the smallest D~, more entries at the cut than the
+    survivors' pass orders (GF_PLACED = 512) -- the query must go to the literal kernels and come back with the
+    reference's answer (TopKHeap order among equal distances, Index.scala:265-299)."""
+    monkeypatch.setenv("GULON_GROUPED_STATS", "1")
+    n, d, groups, m, k, limit, B, K = 40000, 16, 200, 8, 64, 60, 20, 10
+    rng = np.random.default_rng(77)
+    X = (rng.standard_normal((n, d)) + 3.0 * rng.integers(0, 4, (n, 1))).astype(np.float32)
+    X[5000:5700] = X[17]
+    dm = g.DeviceMatrix.from_host(X)
+    coarse = g.KMeans.compute_clusters(g.Vectors(dm), g.KMeansConfig(groups, 2))
+    gv = g.group(dm, coarse)
+    pq = g.ProductQuantizer.apply(gv.residuals, g.ProductQuantizerConfig(k, m, 2))
+    R, cents, offsets = _oracle_side(oracle, X, coarse, gv, pq, n)
+    index = g.Index.grouped(gv, pq, g.LimitGroups(limit))
+    Q = np.concatenate([X[17:18], X[5100:5101], X[rng.integers(0, n, B - 2)]])
     oi, od, oc = index.batch_query_raw(K, Q)
     assert "by-group filter" in capfd.readouterr().err
     ei, ed, ec = oracle.grouped_query(index.data.indices(), d, k, pq.flat_centroids(), cents, offsets, Q, K, 0, limit)
