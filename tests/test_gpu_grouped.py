@@ -145,6 +145,7 @@ def test_bad_arguments(g):
     (60000, 24, 300, 8, 64, 90, 3000, False),      # duplicated rows: equal D~ at the cut, ties in the re-ranking
     (60000, 16, 250, 4, 16, 250, 0, True),         # every group searched; a NaN query and a far-away query
     (66000, 8, 11000, 4, 16, 100, 0, False),       # more groups than the group selection keeps keys in registers for
+    (90000, 16, 600, 8, 64, 40, 2500, False),      # LimitGroups(<= 63) over many groups (the wavefront heap), duplicated rows
 ])
 def test_by_group_filter_equals_reference(oracle, g, monkeypatch, capfd, n, d, groups, m, k, limit, dup, bad_query):
     """GroupedIndex.query (Index.scala:265-299) through the by-group pre-selection with 8-bit bound tables
