@@ -59,42 +59,47 @@ struct RegHeap {
   __device__ RegHeap(int cap_, int lane_) : cap(cap_), lane(lane_) {}
   __device__ float val(int i) const { return readlane_f(v, i); }
   __device__ int key(int i) const { return readlane_i(k, i); }
-  __device__ void swp(int a, int b) {
-    const float va = val(a), vb = val(b);
-    const int ka = key(a), kb = key(b);
-    if (lane == a) { v = vb; k = kb; }
-    if (lane == b) { v = va; k = ka; }
-  }
-  __device__ void down(int i) {                             // percolateDown, TopKHeap.scala:30-42
+  // The reference's chains of swaps move ONE entry down (or up) the tree; here that entry travels in registers and
+  // the entries it passes are shifted into the hole it leaves -- the same comparisons in the same order, the same final
+  // arrangement, and three lane reads per level instead of eight (a batch's group selection with LimitGroups(50) over
+  // 1001 groups is ~200 serial updates per query on one wavefront: 234 us of a 0.51 ms batch with the swaps).
+  __device__ void down(int i, float cur, int curk) {        // percolateDown, TopKHeap.scala:30-42; (cur, curk) = entry i
     for (;;) {
       int top = i;
+      float best = cur;
       const int lc = 2 * i + 1, rc = 2 * i + 2;
-      if (lc < size && val(top) < val(lc)) top = lc;
-      if (rc < size && val(top) < val(rc)) top = rc;
+      if (lc < size) { const float a = val(lc); if (best < a) { best = a; top = lc; } }
+      if (rc < size) { const float b = val(rc); if (best < b) { best = b; top = rc; } }
       if (top == i) break;
-      swp(i, top);
+      const int tk = key(top);
+      if (lane == i) { v = best; k = tk; }
       i = top;
     }
+    if (lane == i) { v = cur; k = curk; }
   }
   __device__ int del() {                                    // delete, TopKHeap.scala:57-67
     size -= 1;
     const int removed = key(0);
     const float lv = val(size);
     const int lk = key(size);
-    if (lane == 0) { v = lv; k = lk; }
-    down(0);
+    down(0, lv, lk);
     return removed;
   }
   __device__ bool would_insert(float x) const { return size < cap || val(0) > x; }
   __device__ void update(int kk, float x) {                 // update, TopKHeap.scala:69-79
     if (size == cap && val(0) > x) del();
     if (size < cap) {
-      if (lane == size) { v = x; k = kk; }
       int i = size;
       while (i > 0) {                                       // percolateUp, TopKHeap.scala:21-28
         const int p = (i - 1) / 2;
-        if (val(i) > val(p)) { swp(i, p); i = p; } else break;
+        const float pv = val(p);
+        if (x > pv) {
+          const int pk = key(p);
+          if (lane == i) { v = pv; k = pk; }
+          i = p;
+        } else break;
       }
+      if (lane == i) { v = x; k = kk; }
       size += 1;
     }
   }
