@@ -446,29 +446,28 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
       float hv = 0.f;
       int hk = 0;
       int size = 0;
-      auto swp = [&](int a, int b) {
-        const float va = readlane_f(hv, a), vb = readlane_f(hv, b);
-        const int ka = readlane_i(hk, a), kb = readlane_i(hk, b);
-        if (lane == a) { hv = vb; hk = kb; }
-        if (lane == b) { hv = va; hk = ka; }
-      };
-      auto down = [&](int i) {                                  // percolateDown, TopKHeap.scala:30-42
+      // (the reference's chains of swaps move ONE entry down or up the tree: it travels in registers here and the
+      // entries it passes are shifted into the hole it leaves -- the same comparisons in the same order, the same final
+      // arrangement, three lane reads per level instead of eight)
+      auto down = [&](int i, float cur, int curk) {             // percolateDown, TopKHeap.scala:30-42; (cur, curk) = entry i
         for (;;) {
           int top = i;
+          float best = cur;
           const int lc = 2 * i + 1, rc = 2 * i + 2;
-          if (lc < size && readlane_f(hv, top) < readlane_f(hv, lc)) top = lc;
-          if (rc < size && readlane_f(hv, top) < readlane_f(hv, rc)) top = rc;
+          if (lc < size) { const float a = readlane_f(hv, lc); if (best < a) { best = a; top = lc; } }
+          if (rc < size) { const float b = readlane_f(hv, rc); if (best < b) { best = b; top = rc; } }
           if (top == i) break;
-          swp(i, top);
+          const int tk = readlane_i(hk, top);
+          if (lane == i) { hv = best; hk = tk; }
           i = top;
         }
+        if (lane == i) { hv = cur; hk = curk; }
       };
       auto del = [&]() {                                        // delete, TopKHeap.scala:57-67
         size -= 1;
         const float lv = readlane_f(hv, size);
         const int lk = readlane_i(hk, size);
-        if (lane == 0) { hv = lv; hk = lk; }
-        down(0);
+        down(0, lv, lk);
       };
       for (int base = 0; base < kept; base += 64) {
         const float ev = base + lane < kept ? sv[base + lane] : 0.f;
@@ -479,12 +478,17 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
           const int kk = readlane_i(ek, e);
           if (size == K && readlane_f(hv, 0) > v) del();        // update, TopKHeap.scala:69-79
           if (size < K) {
-            if (lane == size) { hv = v; hk = kk; }
             int i = size;
             while (i > 0) {                                     // percolateUp, TopKHeap.scala:21-28
               const int p = (i - 1) / 2;
-              if (readlane_f(hv, i) > readlane_f(hv, p)) { swp(i, p); i = p; } else break;
+              const float pv = readlane_f(hv, p);
+              if (v > pv) {
+                const int pk = readlane_i(hk, p);
+                if (lane == i) { hv = pv; hk = pk; }
+                i = p;
+              } else break;
             }
+            if (lane == i) { hv = v; hk = kk; }
             size += 1;
           }
         }
