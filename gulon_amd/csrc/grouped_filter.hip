@@ -120,41 +120,48 @@ __global__ void gf_gnorm(const float *__restrict__ gcent, int g, int d, float *_
 __global__ __launch_bounds__(256) void gf_tiles(const int *__restrict__ gcnt, int g, int B, const int *__restrict__ bounds,
                                                 const float *__restrict__ xnlo, const int *__restrict__ pairs,
                                                 GfTile *__restrict__ tiles, int *__restrict__ meta) {
-  __shared__ int s_t[8], s_p[4];
-  const int tid = threadIdx.x, c = blockIdx.x * 256 + tid;
-  const int c0 = blockIdx.x * 256;
+  // 64 groups per workgroup, four threads per group: a group's ~4 tiles are written side by side (one thread per group
+  // wrote them one after the other, sixteen dependent loads each: 30 us at 1001 groups)
+  __shared__ int s_w[4], s_p[4], s_t0[GF_TG], s_n[GF_TG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c0 = blockIdx.x * GF_TG;
   int before = 0, pbefore = 0;                 // tiles (and pairs) of the groups in front of this workgroup's
   for (int e = tid; e < c0; e += 256) { const int n = gcnt[e]; before += (n + GF_QT - 1) / GF_QT; pbefore += n; }
-  const int cnt = c < g ? gcnt[c] : 0;
-  const int mine = (cnt + GF_QT - 1) / GF_QT;
-  // inclusive prefix of `mine` over the workgroup + the total of `before`
-  int incl = mine, bsum = before, psum = cnt + pbefore;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o);
-    if ((tid & 63) >= o) incl += up;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { bsum += __shfl_xor(bsum, o); psum += __shfl_xor(psum, o); }
-  if ((tid & 63) == 63) s_t[tid >> 6] = incl;
-  if ((tid & 63) == 0) { s_t[4 + (tid >> 6)] = bsum; s_p[tid >> 6] = psum; }
+  for (int o = 32; o >= 1; o >>= 1) { before += __shfl_xor(before, o); pbefore += __shfl_xor(pbefore, o); }
+  if (lane == 0) { s_w[tid >> 6] = before; s_p[tid >> 6] = pbefore; }
   __syncthreads();
-  int base = s_t[4] + s_t[5] + s_t[6] + s_t[7];
-  for (int w = 0; w < (tid >> 6); w++) base += s_t[w];
-  const int t1 = base + incl, t0 = t1 - mine;
-  if (blockIdx.x == gridDim.x - 1 && tid == 255) {
-    // (pairs: counted only for the debugging aid's report)
-    meta[0] = t1;
-    meta[1] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+  if (tid < GF_TG) {                           // one wavefront: lane = group
+    const int c = c0 + tid;
+    const int cnt = c < g ? gcnt[c] : 0;
+    const int mine = (cnt + GF_QT - 1) / GF_QT;
+    int incl = mine, psum = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (tid >= o) incl += up;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) psum += __shfl_xor(psum, o);
+    const int base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    s_t0[tid] = base + incl - mine;
+    s_n[tid] = cnt;
+    if (blockIdx.x == gridDim.x - 1 && tid == GF_TG - 1) {
+      meta[0] = base + incl;
+      meta[1] = s_p[0] + s_p[1] + s_p[2] + s_p[3] + psum;   // (pairs: counted only for the debugging aid's report)
+    }
   }
+  __syncthreads();
+  const int gi = tid >> 2, c = c0 + gi;
   if (c >= g) return;
-  for (int t = t0; t < t1; t++) {
-    const int first = (t - t0) * GF_QT;
+  const int cnt = s_n[gi], t0 = s_t0[gi], nt = (cnt + GF_QT - 1) / GF_QT;
+  for (int ts = tid & 3; ts < nt; ts += 4) {
+    const int first = ts * GF_QT;
     GfTile T;
     T.c = c; T.nq = min(GF_QT, cnt - first); T.r0 = bounds[c]; T.r1 = bounds[c + 1]; T.xl = xnlo[c];
     T.pad[0] = T.pad[1] = T.pad[2] = 0;
     for (int i = 0; i < GF_QT; i++) T.qid[i] = pairs[(size_t)c * B + first + min(i, T.nq - 1)];
-    tiles[t] = T;
+    tiles[t0 + ts] = T;
   }
 }
 
@@ -769,7 +776,7 @@ void group_filter_run(GroupFilter &gf, const uint8_t *codes, int ng, int vec, in
     hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_q, st, P, pq_cents, from, sdim, m, m_pad, k, d, Q, cdist, g, gf.gnorm.p, gf.gnmax, gf.xnlo.p, nn,
                        nn_stride, nn_cnt, codes, ng, xnorm, gcent, bounds, xnmax, gf.xn_step, gf.gcnt.p, gf.pairs.p, B, gf.qb.p, gf.qs.p);
   }
-  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, 256)), dim3(256), 0, st, gf.gcnt.p, g, B, bounds, gf.xnlo.p, gf.pairs.p, gf.tiles.p,
+  hipLaunchKernelGGL(gf_tiles, dim3(ceil_div(g, GF_TG)), dim3(256), 0, st, gf.gcnt.p, g, B, bounds, gf.xnlo.p, gf.pairs.p, gf.tiles.p,
                      gf.meta.p);
   HIP_CHECK(hipGetLastError());
   const size_t lds_f = sizeof(uint4) * GF_NT * 256;

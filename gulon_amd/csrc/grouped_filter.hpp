@@ -9,6 +9,7 @@ constexpr int GF_QT = 16;       // queries per tile: one 16-byte table entry hol
 constexpr int GF_CAP = 16384;   // survivors kept per query (more: the query goes to the literal kernels)
 constexpr int GF_WAVES = 16;    // per-query lists written by gf_survivors (= gq_approx_scan's)
 constexpr int GF_LIST = 64;     // entries per list (= gq_approx_scan's)
+constexpr int GF_TG = 64;       // groups per workgroup of gf_tiles (four threads each)
 constexpr int GF_PLACED = 512;  // entries at or below the GF_LIST-th smallest value that gf_survivors orders (more: the literal kernels)
 constexpr int GF_SAMPLE_GROUPS = 16;   // nearest groups whose rows give a query its threshold, at most
 constexpr int GF_SAMPLE_ROWS = 2048;   // ... and rows of them, at most
