@@ -63,6 +63,32 @@ struct RegHeap {
   // the entries it passes are shifted into the hole it leaves -- the same comparisons in the same order, the same final
   // arrangement, and three lane reads per level instead of eight (a batch's group selection with LimitGroups(50) over
   // 1001 groups is ~200 serial updates per query on one wavefront: 234 us of a 0.51 ms batch with the swaps).
+  // percolateDown from the ROOT with every lane working: lane l looks at its own two children and decides where an
+  // entry of value `cur` standing at slot l would go next (the reference's two comparisons, in its order); the path from
+  // the root is then a chase through those answers -- one lane read per level -- and every slot on the path takes its
+  // chosen child's entry at once.
+  __device__ void down_root(float cur, int curk) {
+    const int lc = 2 * lane + 1, rc = 2 * lane + 2;
+    const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (lc & 63), __float_as_int(v)));
+    const float b0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (rc & 63), __float_as_int(v)));
+    const bool ha = lc < size, hb = rc < size;
+    // top = l; if (lc < size && val(top) < val(lc)) top = lc; if (rc < size && val(top) < val(rc)) top = rc;
+    int nxt = -1;
+    float nv = cur;
+    if (ha && nv < a0) { nv = a0; nxt = lc; }
+    if (hb && nv < b0) { nv = b0; nxt = rc; }
+    const int kc = __builtin_amdgcn_ds_bpermute(4 * (max(nxt, 0) & 63), k);
+    unsigned long long path = 0ull;
+    int node = 0;
+    for (;;) {
+      const int n2 = readlane_i(nxt, node);
+      if (n2 < 0) break;
+      path |= 1ull << node;
+      node = n2;
+    }
+    if ((path >> lane) & 1ull) { v = nv; k = kc; }
+    if (lane == node) { v = cur; k = curk; }
+  }
   __device__ void down(int i, float cur, int curk) {        // percolateDown, TopKHeap.scala:30-42; (cur, curk) = entry i
     for (;;) {
       int top = i;
@@ -82,7 +108,11 @@ struct RegHeap {
     const int removed = key(0);
     const float lv = val(size);
     const int lk = key(size);
+#ifdef GULON_REGHEAP_SERIAL_DOWN
     down(0, lv, lk);
+#else
+    down_root(lv, lk);
+#endif
     return removed;
   }
   __device__ bool would_insert(float x) const { return size < cap || val(0) > x; }
