@@ -446,28 +446,35 @@ __global__ __launch_bounds__(256) void rp_heap(const int *__restrict__ packs, in
       float hv = 0.f;
       int hk = 0;
       int size = 0;
-      // (the reference's chains of swaps move ONE entry down or up the tree: it travels in registers here and the
-      // entries it passes are shifted into the hole it leaves -- the same comparisons in the same order, the same final
-      // arrangement, three lane reads per level instead of eight)
-      auto down = [&](int i, float cur, int curk) {             // percolateDown, TopKHeap.scala:30-42; (cur, curk) = entry i
+      // percolateDown from the root with every lane working (grouped.hip's RegHeap::down_root): lane l decides from its
+      // own two children where an entry of value `cur` standing at slot l would go next -- the reference's two
+      // comparisons in its order --, the path from the root is a chase through those answers and the slots on it take
+      // their chosen child's entry at once
+      auto down_root = [&](float cur, int curk) {
+        const int lc = 2 * lane + 1, rc = 2 * lane + 2;
+        const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (lc & 63), __float_as_int(hv)));
+        const float b0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (rc & 63), __float_as_int(hv)));
+        int nxt = -1;
+        float nv = cur;
+        if (lc < size && nv < a0) { nv = a0; nxt = lc; }
+        if (rc < size && nv < b0) { nv = b0; nxt = rc; }
+        const int kc = __builtin_amdgcn_ds_bpermute(4 * (max(nxt, 0) & 63), hk);
+        unsigned long long path = 0ull;
+        int node = 0;
         for (;;) {
-          int top = i;
-          float best = cur;
-          const int lc = 2 * i + 1, rc = 2 * i + 2;
-          if (lc < size) { const float a = readlane_f(hv, lc); if (best < a) { best = a; top = lc; } }
-          if (rc < size) { const float b = readlane_f(hv, rc); if (best < b) { best = b; top = rc; } }
-          if (top == i) break;
-          const int tk = readlane_i(hk, top);
-          if (lane == i) { hv = best; hk = tk; }
-          i = top;
+          const int n2 = readlane_i(nxt, node);
+          if (n2 < 0) break;
+          path |= 1ull << node;
+          node = n2;
         }
-        if (lane == i) { hv = cur; hk = curk; }
+        if ((path >> lane) & 1ull) { hv = nv; hk = kc; }
+        if (lane == node) { hv = cur; hk = curk; }
       };
       auto del = [&]() {                                        // delete, TopKHeap.scala:57-67
         size -= 1;
         const float lv = readlane_f(hv, size);
         const int lk = readlane_i(hk, size);
-        down(0, lv, lk);
+        down_root(lv, lk);
       };
       for (int base = 0; base < kept; base += 64) {
         const float ev = base + lane < kept ? sv[base + lane] : 0.f;
